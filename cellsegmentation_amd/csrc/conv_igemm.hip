@@ -1,0 +1,661 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4): forward + data-gradient share one kernel, the
+// weight gradient has its own.  Replaces the ATen conv2d / conv2d_backward dispatched by
+// model/resnet.py:20,23,51,53,55,111,183,198,164 (and their autograd backward).
+//
+// GEMM view (fwd / dgrad):  D[m][o] = sum_q A[m][q] * B[o][q]
+//   m  = destination pixel (n, dy, dx)            -> rows of the NHWC destination tensor
+//   o  = destination channel
+//   q  = (tap, source-channel chunk), 16 bytes of K per chunk
+//   A  = gathered on the fly from the NHWC source tensor (im2col never materialised)
+//   B  = weights stored [o][tap][c] (K contiguous)
+// The source coordinate of tap (kh,kw) for destination (dy,dx) is
+//   t = d*mul + off0 + sgn*k;  valid iff t % div == 0 and 0 <= t/div < extent
+// fwd:   mul=stride, off0=-pad, sgn=+1, div=1        (source = x, dest = y)
+// dgrad: mul=1,      off0=+pad, sgn=-1, div=stride   (source = dy, dest = dx)
+//
+// Tile: BM x BN outputs per 256-thread workgroup (4 waves as 2x2), K-step = 8 chunks (128 B per
+// row), register-staged double-buffered LDS, XOR-swizzled 16-byte slots so ds_read_b128 of an
+// MFMA operand column is bank-conflict free.  MFMA: v_mfma_f32_32x32x16_bf16 (bf16) or the exact
+// v_mfma_f32_32x32x2_f32 (fp32 parity mode); one 16-byte chunk per lane feeds 1 resp. 4 MFMAs.
+// Epilogue: accumulators -> LDS (fp32) -> 8 channels per thread, fully vectorised
+// scale/shift/residual/activation/mask + store + optional per-channel statistics.
+#include "cs_common.h"
+
+namespace {
+
+struct IgemmParams {
+    const void* src;
+    const void* wgt;
+    void* dst;
+    const float* scale;
+    const float* shift;
+    const void* residual;
+    const void* mask;
+    float* colsum;    // fp32 [NOUT]  (dgrad: sums of stored output)
+    double* stats;    // fp64 [2][NOUT] (fwd: sum, sum of squares of stored output)
+    int SH, SW, SC;   // source extents, stored channels
+    int DH, DW;       // destination spatial extents
+    int NOUT;         // destination channels
+    int R, S;
+    int mul, div, off0, sgn;
+    int act;
+    long long M;      // N*DH*DW
+    int Qtot;         // R*S*SCc
+    int SCc;          // SC / chunk
+};
+
+__device__ __forceinline__ int swz(int row, int c) { return row * 8 + (c ^ ((row >> 1) & 7)); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
+        union { uint4 u; bf16x8 v; } ca, cb;
+        ca.u = a; cb.u = b;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca.v, cb.v, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+    constexpr int CE = Elem<T>::kChunk;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 8;  // uint4 per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* smem = reinterpret_cast<uint4*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- per-thread gather bookkeeping: fixed rows, walking (kh,kw,cc) ----
+    const int lc = tid & 7;    // chunk column inside the K-step
+    const int lr = tid >> 3;   // 0..31
+    long long rowbase[AI];     // pixel index of (n,0,0) in the source tensor, or -1 if row invalid
+    int ty[AI], tx[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const long long m = m0 + lr + 32 * i;
+        if (m < p.M) {
+            const long long img = m / ((long long)p.DH * p.DW);
+            const int rem = (int)(m - img * (long long)p.DH * p.DW);
+            const int dy = rem / p.DW;
+            const int dx = rem - dy * p.DW;
+            rowbase[i] = img * (long long)p.SH * p.SW;
+            ty[i] = dy * p.mul + p.off0;
+            tx[i] = dx * p.mul + p.off0;
+        } else {
+            rowbase[i] = -1;
+            ty[i] = 0; tx[i] = 0;
+        }
+    }
+    // walking position of this thread's chunk column in K space
+    int q = lc;
+    int tap = q / p.SCc;
+    int cc = q - tap * p.SCc;
+    int kh = tap / p.S;
+    int kw = tap - kh * p.S;
+
+    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+    const long long wrow_elems = (long long)p.Qtot * CE;
+
+    uint4 ra[AI], rb[BI];
+    auto gload = [&]() {
+        const bool qok = q < p.Qtot;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qok && rowbase[i] >= 0) {
+                int y = ty[i] + p.sgn * kh;
+                int x = tx[i] + p.sgn * kw;
+                bool ok = (y >= 0) && (x >= 0);
+                if (p.div > 1) {
+                    ok = ok && (y % p.div == 0) && (x % p.div == 0);
+                    y /= p.div; x /= p.div;
+                }
+                ok = ok && (y < p.SH) && (x < p.SW);
+                if (ok) {
+                    const long long pix = rowbase[i] + (long long)y * p.SW + x;
+                    v = *reinterpret_cast<const uint4*>(src + pix * p.SC + cc * CE);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int o = n0 + lr + 32 * j;
+            if (qok && o < p.NOUT) v = *reinterpret_cast<const uint4*>(wgt + (long long)o * wrow_elems + (long long)q * CE);
+            rb[j] = v;
+        }
+    };
+    auto advance = [&]() {
+        q += 8;
+        cc += 8;
+        while (cc >= p.SCc) {
+            cc -= p.SCc;
+            ++kw;
+            if (kw == p.S) { kw = 0; ++kh; }
+        }
+    };
+    auto lstore = [&](int buf) {
+        uint4* As = smem + buf * STAGE;
+        uint4* Bs = As + BM * 8;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) As[swz(lr + 32 * i, lc)] = ra[i];
+#pragma unroll
+        for (int j = 0; j < BI; ++j) Bs[swz(lr + 32 * j, lc)] = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.Qtot + 7) / 8;
+    gload();
+    advance();
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = (ks + 1) < nk;
+        if (more) { gload(); advance(); }
+        const uint4* As = smem + (ks & 1) * STAGE;
+        const uint4* Bs = As + BM * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = 2 * kk + hh;
+            uint4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[swz(wm * (BM / 2) + i * 32 + l31, c)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[swz(wn * (BN / 2) + j * 32 + l31, c)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        if (more) lstore((ks + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS fp32 [BM][BN] (aliases the staging buffers) ----
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int col = wn * (BN / 2) + j * 32 + l31;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int CG = BN / 8;              // 8-channel groups per tile row
+    constexpr int ITERS = BM * BN / 8 / 256;
+    const int cg = tid % CG;
+    const int o = n0 + cg * 8;
+    const bool ook = o < p.NOUT;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = (p.scale && ook) ? p.scale[o + e] : 1.f;
+        sh[e] = (p.shift && ook) ? p.shift[o + e] : 0.f;
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    const T* __restrict__ msk = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = it * (256 / CG) + tid / CG;
+        const long long m = m0 + row;
+        if (m < p.M && ook) {
+            float v[8];
+            const float4 c0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+            const float4 c1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            const long long off = m * p.NOUT + o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (res) {
+                float r8[8];
+                load8<T>(res + off, r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r8[e];
+            }
+            if (p.act == CS_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (p.act == CS_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+            }
+            if (msk) {
+                float k8[8];
+                load8<T>(msk + off, k8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
+            }
+            store8<T>(dst + off, v);
+            if (p.colsum || p.stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // statistics are those of the STORED (rounded) values
+                    const float w = to_f32<T>(from_f32<T>(v[e]));
+                    s1[e] += w;
+                    s2[e] += w * w;
+                }
+            }
+        }
+    }
+    if (p.colsum || p.stats) {
+        // lanes with equal (lane % CG) own the same channels: fold them, then one atomic per wave.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int offl = 32; offl >= CG; offl >>= 1) {
+                s1[e] += __shfl_xor(s1[e], offl, 64);
+                s2[e] += __shfl_xor(s2[e], offl, 64);
+            }
+        }
+        if (lane < CG && ook) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (p.colsum) atomicAdd(p.colsum + o + e, s1[e]);
+                if (p.stats) {
+                    atomicAdd(p.stats + o + e, (double)s1[e]);
+                    atomicAdd(p.stats + p.NOUT + o + e, (double)s2[e]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+int launch_igemm(const IgemmParams& p, hipStream_t st) {
+    constexpr size_t stage_bytes = 2ull * (BM + BN) * 8 * 16;
+    constexpr size_t epi_bytes = (size_t)BM * BN * 4;
+    constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.NOUT + BN - 1) / BN), 1);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), grid, dim3(256), lds, st, p);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+template <typename T>
+int dispatch_igemm(const IgemmParams& p, hipStream_t st) {
+    // Tile choice: wide-N tiles when there are enough output channels; shrink BM when the grid
+    // would not fill the 256 CUs.
+    const long long mt128 = (p.M + 127) / 128;
+    if (p.NOUT > 64) {
+        const long long blocks = mt128 * ((p.NOUT + 127) / 128);
+        if (blocks >= 384) return launch_igemm<T, 128, 128>(p, st);
+        return launch_igemm<T, 64, 128>(p, st);
+    }
+    if (mt128 >= 384) return launch_igemm<T, 128, 64>(p, st);
+    return launch_igemm<T, 64, 64>(p, st);
+}
+
+int check_geom(const CsConvGeom* g, int dtype) {
+    CS_CHECK_ARG(g != nullptr, "conv: geometry is NULL");
+    CS_CHECK_ARG(dtype == CS_F32 || dtype == CS_BF16, "conv: dtype must be CS_F32 or CS_BF16");
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    CS_CHECK_ARG(g->N > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->K > 0, "conv: non-positive extent");
+    CS_CHECK_ARG(g->R > 0 && g->S > 0 && g->stride > 0 && g->pad >= 0, "conv: bad kernel/stride/pad");
+    CS_CHECK_ARG(g->C % ce == 0, "conv: stored input channels must be a multiple of the 16-byte chunk");
+    CS_CHECK_ARG(g->K % 8 == 0, "conv: stored output channels must be a multiple of 8");
+    CS_CHECK_ARG(g->P == (g->H + 2 * g->pad - g->R) / g->stride + 1, "conv: P does not match H/R/stride/pad");
+    CS_CHECK_ARG(g->Q == (g->W + 2 * g->pad - g->S) / g->stride + 1, "conv: Q does not match W/S/stride/pad");
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
+                             const float* shift, const void* residual, int act, void* y, double* stats, void* stream) {
+    int rc = check_geom(g, dtype);
+    if (rc != CS_OK) return rc;
+    CS_CHECK_ARG(x && w_khwc && y, "conv2d_fwd: NULL tensor");
+    IgemmParams p{};
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    p.src = x; p.wgt = w_khwc; p.dst = y;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.mask = nullptr;
+    p.colsum = nullptr; p.stats = stats;
+    p.SH = g->H; p.SW = g->W; p.SC = g->C;
+    p.DH = g->P; p.DW = g->Q; p.NOUT = g->K;
+    p.R = g->R; p.S = g->S;
+    p.mul = g->stride; p.div = 1; p.off0 = -g->pad; p.sgn = 1;
+    p.act = act;
+    p.M = (long long)g->N * g->P * g->Q;
+    p.SCc = g->C / ce;
+    p.Qtot = g->R * g->S * p.SCc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == CS_F32 ? dispatch_igemm<float>(p, st) : dispatch_igemm<bf16_t>(p, st);
+}
+
+extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
+                               const void* mask, void* dx, float* colsum, void* stream) {
+    int rc = check_geom(g, dtype);
+    if (rc != CS_OK) return rc;
+    CS_CHECK_ARG(dy && w_chwk && dx, "conv2d_dgrad: NULL tensor");
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    CS_CHECK_ARG(g->K % ce == 0, "conv2d_dgrad: stored K must be a chunk multiple");
+    CS_CHECK_ARG(g->C % 8 == 0, "conv2d_dgrad: stored C must be a multiple of 8");
+    IgemmParams p{};
+    p.src = dy; p.wgt = w_chwk; p.dst = dx;
+    p.scale = nullptr; p.shift = nullptr; p.residual = add; p.mask = mask;
+    p.colsum = colsum; p.stats = nullptr;
+    p.SH = g->P; p.SW = g->Q; p.SC = g->K;
+    p.DH = g->H; p.DW = g->W; p.NOUT = g->C;
+    p.R = g->R; p.S = g->S;
+    p.mul = 1; p.div = g->stride; p.off0 = g->pad; p.sgn = -1;
+    p.act = CS_ACT_NONE;
+    p.M = (long long)g->N * g->H * g->W;
+    p.SCc = g->K / ce;
+    p.Qtot = g->R * g->S * p.SCc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == CS_F32 ? dispatch_igemm<float>(p, st) : dispatch_igemm<bf16_t>(p, st);
+}
+
+// =============================================================================================
+// Weight gradient:  dW[k][q] += sum_m dy[m][k] * xcol[m][q]      (GEMM M=K_out, N=taps*C, K=pixels)
+// Both operands are pixel-major in memory, i.e. "transposed" for the MFMA (a lane needs
+// consecutive pixels of ONE channel).  LDS keeps the natural [pixel][channel] image; operands are
+// fetched either element-wise (f32: one ds_read_b32 per MFMA operand; bf16 safe path: ds_read_u16)
+// or, for bf16, with the gfx950 transposing read ds_read_b64_tr_b16.
+// Split-K over pixel ranges (gridDim.z); partial tiles are combined with fp32 atomics.
+// =============================================================================================
+namespace {
+
+struct WgradParams {
+    const void* x;    // source activations NHWC [N][H][W][C]
+    const void* dy;   // [M][KO]
+    float* dw;        // [KO][QE] fp32, QE = R*S*C
+    int H, W, C;
+    int P, Q;
+    int KO;
+    int R, S, stride, pad;
+    long long M;
+    int QE;           // R*S*C (elements)
+    int SCc;          // C / chunk
+    long long m_per_split;   // multiple of 32
+};
+
+template <typename T, int BM, int BN, bool TR>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    constexpr int CE = Elem<T>::kChunk;
+    constexpr int BKP = 32;                  // pixels per K-step
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int ACPR = BM / CE;            // A chunks per pixel row
+    constexpr int BCPR = BN / CE;
+    constexpr int AI = BKP * ACPR / 256;     // chunks per thread
+    constexpr int BI = BKP * BCPR / 256;
+    constexpr int ASTAGE = BKP * BM;         // elements
+    constexpr int BSTAGE = BKP * BN;
+    static_assert(AI >= 1 && BI >= 1, "tile too small");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const int k0 = blockIdx.x * BM;          // output-channel tile origin
+    const int q0 = blockIdx.y * BN;          // K-space (tap,c) element origin
+    const long long mbeg = (long long)blockIdx.z * p.m_per_split;
+    long long mend = mbeg + p.m_per_split;
+    if (mend > p.M) mend = p.M;
+    if (mbeg >= mend) return;
+
+    const T* __restrict__ xs = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ gs = reinterpret_cast<const T*>(p.dy);
+
+    // A operand (dy): chunk column fixed per thread
+    const int ac = tid % ACPR;
+    const int ar = tid / ACPR;               // + (256/ACPR)*i
+    const int a_ch = k0 + ac * CE;
+    const bool a_ok = a_ch < p.KO;
+    // B operand (im2col of x): chunk column fixed per thread -> fixed tap and channel chunk
+    const int bc = tid % BCPR;
+    const int br = tid / BCPR;
+    const int bq = q0 + bc * CE;             // element index in K space
+    const bool b_ok = bq < p.QE;
+    int b_kh = 0, b_kw = 0, b_c = 0;
+    if (b_ok) {
+        const int tap = bq / p.C;
+        b_c = bq - tap * p.C;
+        b_kh = tap / p.S;
+        b_kw = tap - b_kh * p.S;
+    }
+    // walking (n, oy, ox) for each of this thread's B rows
+    long long bn_[BI];
+    int boy[BI], box[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const long long m = mbeg + br + (256 / BCPR) * i;
+        const long long img = m / ((long long)p.P * p.Q);
+        const int rem = (int)(m - img * (long long)p.P * p.Q);
+        bn_[i] = img;
+        boy[i] = rem / p.Q;
+        box[i] = rem - boy[i] * p.Q;
+    }
+
+    uint4 ra[AI], rb[BI];
+    long long mstep = mbeg;
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const long long m = mstep + ar + (256 / ACPR) * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a_ok && m < mend) v = *reinterpret_cast<const uint4*>(gs + m * p.KO + a_ch);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const long long m = mstep + br + (256 / BCPR) * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b_ok && m < mend) {
+                const int iy = boy[i] * p.stride - p.pad + b_kh;
+                const int ix = box[i] * p.stride - p.pad + b_kw;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const long long pix = (bn_[i] * p.H + iy) * (long long)p.W + ix;
+                    v = *reinterpret_cast<const uint4*>(xs + pix * p.C + b_c);
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto advance = [&]() {
+        mstep += BKP;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            box[i] += BKP;
+            while (box[i] >= p.Q) {
+                box[i] -= p.Q;
+                if (++boy[i] == p.P) { boy[i] = 0; ++bn_[i]; }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        T* As = smem + buf * (ASTAGE + BSTAGE);
+        T* Bs = As + ASTAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<uint4*>(As + (ar + (256 / ACPR) * i) * BM + ac * CE) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            *reinterpret_cast<uint4*>(Bs + (br + (256 / BCPR) * i) * BN + bc * CE) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (int)((mend - mbeg + BKP - 1) / BKP);
+    gload();
+    advance();
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = (ks + 1) < nk;
+        if (more) { gload(); advance(); }
+        const T* As = smem + (ks & 1) * (ASTAGE + BSTAGE);
+        const T* Bs = As + ASTAGE;
+        if constexpr (sizeof(T) == 4) {
+            // f32: v_mfma_f32_32x32x2_f32 wants A[i][k=hh], B[k=hh][j]: one dword each
+#pragma unroll
+            for (int s = 0; s < BKP / 2; ++s) {
+                const int kr = 2 * s + hh;
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = reinterpret_cast<const float*>(As)[kr * BM + wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = reinterpret_cast<const float*>(Bs)[kr * BN + wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < BKP / 16; ++s) {
+                union Frag { bf16x8 v; unsigned short h[8]; s16x4 q[2]; };
+                Frag a[TM], b[TN];
+                if constexpr (TR) {
+                    // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(channel) block, delivered
+                    // column-major: lane i16 gets the 4 k-values of channel i16.
+                    const int g16 = lane >> 4;          // 0..3 ; (g16 & 1) selects channels 0-15 / 16-31
+                    const int i16 = lane & 15;
+                    const int qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int kr = 16 * s + 8 * hh + 4 * u + qq;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const unsigned short* ap = reinterpret_cast<const unsigned short*>(As) + kr * BM +
+                                                       wm * (BM / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
+                            a[i].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(ap));
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const unsigned short* bp = reinterpret_cast<const unsigned short*>(Bs) + kr * BN +
+                                                       wn * (BN / 2) + j * 32 + 16 * (g16 & 1) + 4 * pp;
+                            b[j].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(bp));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kr = 16 * s + 8 * hh + e;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            a[i].h[e] = reinterpret_cast<const unsigned short*>(As)[kr * BM + wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            b[j].h[e] = reinterpret_cast<const unsigned short*>(Bs)[kr * BN + wn * (BN / 2) + j * 32 + l31];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) lstore((ks + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- split-K combine: fp32 atomics, 32 consecutive q per half-wave (128-B segments) ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int qe = q0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = k0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ko < p.KO && qe < p.QE) atomicAdd(p.dw + (long long)ko * p.QE + qe, acc[i][j][r]);
+            }
+        }
+}
+
+template <typename T, int BM, int BN, bool TR>
+int launch_wgrad(WgradParams p, hipStream_t st) {
+    const int tiles = cs_ceil_div(p.KO, BM) * cs_ceil_div(p.QE, BN);
+    // aim for ~4 workgroups per CU over the whole grid, at least 4 K-steps per slice
+    long long want = (1024 + tiles - 1) / tiles;
+    long long max_split = (p.M + 127) / 128;
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    long long per = (p.M + want - 1) / want;
+    per = ((per + 31) / 32) * 32;
+    const int nsplit = (int)((p.M + per - 1) / per);
+    p.m_per_split = per;
+    constexpr size_t lds = 2ull * 32 * (BM + BN) * sizeof(T);
+    dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), nsplit);
+    hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
+                               int use_tr_read, void* stream) {
+    int rc = check_geom(g, dtype);
+    if (rc != CS_OK) return rc;
+    CS_CHECK_ARG(x && dy && dw_khwc, "conv2d_wgrad: NULL tensor");
+    WgradParams p{};
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    p.x = x; p.dy = dy; p.dw = dw_khwc;
+    p.H = g->H; p.W = g->W; p.C = g->C;
+    p.P = g->P; p.Q = g->Q; p.KO = g->K;
+    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
+    p.M = (long long)g->N * g->P * g->Q;
+    p.QE = g->R * g->S * g->C;
+    p.SCc = g->C / ce;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CS_F32) {
+        if (g->K > 64) return launch_wgrad<float, 128, 128, false>(p, st);
+        return launch_wgrad<float, 64, 128, false>(p, st);
+    }
+    if (use_tr_read) {
+        if (g->K > 64) return launch_wgrad<bf16_t, 128, 128, true>(p, st);
+        return launch_wgrad<bf16_t, 64, 128, true>(p, st);
+    }
+    if (g->K > 64) return launch_wgrad<bf16_t, 128, 128, false>(p, st);
+    return launch_wgrad<bf16_t, 64, 128, false>(p, st);
+}

@@ -1,0 +1,114 @@
+// Shared device/host helpers for libcellseg_hip.so (gfx950 / CDNA4 only).
+//
+// Storage convention for every activation tensor on the hot path:
+//   NHWC, element type T in {float, bf16}, channel count padded to a multiple of one
+//   16-byte "chunk" (4 floats or 8 bf16), so every (pixel, channel-chunk) is one aligned
+//   16-byte global access.  fp32 is the parity mode (exact-f32 MFMA), bf16 the throughput mode.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/cellseg_hip.h"
+
+typedef __bf16 bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kChunk = 4;   // elements per 16-byte chunk
+    static constexpr int kDtype = CS_F32;
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kChunk = 8;
+    static constexpr int kDtype = CS_BF16;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) {
+    return __uint_as_float(lo16 << 16);
+}
+
+// 8 consecutive elements -> 8 floats (p must be 16-byte aligned for bf16, 32 for the pair of float4s
+// is NOT required: two independent 16-byte loads).
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+    union { bf16_t h[2]; uint32_t u; } cv;
+    cv.h[0] = (bf16_t)lo;
+    cv.h[1] = (bf16_t)hi;
+    return cv.u;
+}
+
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]);
+    o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- host side error plumbing (cs_api.cpp owns the storage) ----
+extern "C" void cs_set_error_(const char* msg);
+#define CS_CHECK_ARG(cond, msg)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            cs_set_error_(msg);                         \
+            return CS_ERR_INVALID_ARG;                  \
+        }                                               \
+    } while (0)
+#define CS_LAUNCH_CHECK()                               \
+    do {                                                \
+        hipError_t e__ = hipGetLastError();             \
+        if (e__ != hipSuccess) {                        \
+            cs_set_error_(hipGetErrorString(e__));      \
+            return CS_ERR_LAUNCH;                       \
+        }                                               \
+    } while (0)
+
+static inline int cs_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

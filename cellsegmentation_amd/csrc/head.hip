@@ -1,0 +1,181 @@
+// Heads and losses (tiny, fp32): Linear (model/resnet.py:126,137,140,150,360), CrossEntropy*gamma
+// (train/train.py:34,80), softmax prob of class 1 (inference.py:24-27), MSE / weighted MSE
+// (train/losses.py:5-29, metrics/metrics.py:23-33), Dice (train/losses.py:44-62,
+// metrics/metrics.py:36-53).
+#include "cs_common.h"
+
+namespace {
+
+// one wave per output element y[m][n]
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int M, int N,
+                                                         int K, int act) {
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= (long long)M * N) return;
+    const int m = (int)(wave / N), n = (int)(wave % N);
+    const float* xr = x + (long long)m * K;
+    const float* wr = w + (long long)n * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += xr[k] * wr[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + (b ? b[n] : 0.f);
+        if (act == CS_ACT_RELU) v = v > 0.f ? v : 0.f;
+        y[(long long)m * N + n] = v;
+    }
+}
+
+// dx[m][k] = sum_n g[m][n] w[n][k]
+__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ w, float* __restrict__ dx, int M, int N,
+                                                        int K, int act) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * K) return;
+    const int m = (int)(idx / K), k = (int)(idx % K);
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float g = dy[(long long)m * N + n];
+        if (act == CS_ACT_RELU && !(y[(long long)m * N + n] > 0.f)) g = 0.f;
+        acc += g * w[(long long)n * K + k];
+    }
+    dx[idx] = acc;
+}
+
+// dw[n][k] = sum_m g[m][n] x[m][k];  db[n] = sum_m g[m][n] (k == 0 thread)
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ x, float* __restrict__ dw,
+                                                        float* __restrict__ db, int M, int N, int K, int act,
+                                                        int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx % K);
+    float acc = 0.f, accb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float g = dy[(long long)m * N + n];
+        if (act == CS_ACT_RELU && !(y[(long long)m * N + n] > 0.f)) g = 0.f;
+        acc += g * x[(long long)m * K + k];
+        accb += g;
+    }
+    dw[idx] = accumulate ? dw[idx] + acc : acc;
+    if (db && k == 0) db[n] = accumulate ? db[n] + accb : accb;
+}
+
+// rows handled one per thread (C is 2 or 7 here); block partial sums -> one atomic per block
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         float gamma, float* __restrict__ loss, float* __restrict__ dlogits,
+                                                         int M, int C) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    float li = 0.f;
+    if (m < M) {
+        const float* r = logits + (long long)m * C;
+        float mx = r[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(r[c] - mx);
+        const float lse = mx + logf(se);
+        const int lab = (int)labels[m];
+        li = (lse - r[lab]) * (gamma / (float)M);
+        if (dlogits) {
+            const float gs = gamma / (float)M;
+            for (int c = 0; c < C; ++c) {
+                const float pr = expf(r[c] - lse);
+                dlogits[(long long)m * C + c] = gs * (pr - (c == lab ? 1.f : 0.f));
+            }
+        }
+    }
+    __shared__ float red[4];
+    li = wave_sum(li);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void softmax_prob1_kernel(const float* __restrict__ logits, float* __restrict__ p1, int M, int C) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* r = logits + (long long)m * C;
+    float mx = r[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(r[c] - mx);
+    p1[m] = expf(r[1] - mx) / se;
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, int weighted,
+                                                  float inv, float* __restrict__ loss, float* __restrict__ dx, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    float li = 0.f;
+    if (m < M) {
+        const float d = x[m] - t[m];
+        float w = 1.f;
+        if (weighted) w = t[m] >= 20.f ? logf(t[m]) : t[m];
+        li = w * d * d * inv;
+        if (dx) dx[m] = 2.f * w * d * inv;
+    }
+    __shared__ float red[4];
+    li = wave_sum(li);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act,
+                             void* stream) {
+    CS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long waves = (long long)M * N;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, w, b, y, M, N, K, act);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
+                             float* db, int M, int N, int K, int accumulate, void* stream) {
+    CS_CHECK_ARG(dy && M > 0 && N > 0 && K > 0, "linear_bwd: bad arguments");
+    CS_CHECK_ARG(act != CS_ACT_RELU || y, "linear_bwd: relu needs y");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dx) {
+        CS_CHECK_ARG(w, "linear_bwd: dx needs w");
+        const long long tot = (long long)M * K;
+        hipLaunchKernelGGL(linear_dx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dy, y, w, dx, M, N, K, act);
+        CS_LAUNCH_CHECK();
+    }
+    if (dw) {
+        CS_CHECK_ARG(x, "linear_bwd: dw needs x");
+        const long long tot = (long long)N * K;
+        hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dy, y, x, dw, db, M, N, K, act, accumulate);
+        CS_LAUNCH_CHECK();
+    }
+    return CS_OK;
+}
+
+extern "C" int cs_softmax_ce(const float* logits, const int64_t* labels, float gamma, float* loss, float* dlogits, int M, int C,
+                             void* stream) {
+    CS_CHECK_ARG(logits && labels && loss && M > 0 && C > 1, "softmax_ce: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { cs_set_error_("softmax_ce: memset failed"); return CS_ERR_LAUNCH; }
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, logits, labels, gamma, loss, dlogits, M, C);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_softmax_prob1(const float* logits, float* p1, int M, int C, void* stream) {
+    CS_CHECK_ARG(logits && p1 && M > 0 && C > 1, "softmax_prob1: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(softmax_prob1_kernel, dim3((M + 255) / 256), dim3(256), 0, st, logits, p1, M, C);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_mse(const float* x, const float* t, int weighted, int mean, float* loss, float* dx, int M, void* stream) {
+    CS_CHECK_ARG(x && t && loss && M > 0, "mse: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { cs_set_error_("mse: memset failed"); return CS_ERR_LAUNCH; }
+    const float inv = mean ? 1.f / (float)M : 1.f;
+    hipLaunchKernelGGL(mse_kernel, dim3((M + 255) / 256), dim3(256), 0, st, x, t, weighted, inv, loss, dx, M);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}

@@ -1,0 +1,264 @@
+// Pooling kernels (HBM-bound, 16-byte vector access, 8 channels per thread):
+//   MaxPool2d(3,2,1)                         model/resnet.py:114
+//   AdaptiveAvgPool2d(1)+AdaptiveMaxPool2d(1) model/resnet.py:122-123,130-131,266,274
+#include "cs_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ amax, int N, int H, int W, int C, int P,
+                                                          int Q) {
+    const int CG = C / 8;
+    const long long total = (long long)N * P * Q * CG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        long long t = idx / CG;
+        const int q = (int)(t % Q); t /= Q;
+        const int p = (int)(t % P);
+        const long long n = t / P;
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = p * 2 - 1 + kh;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = q * 2 - 1 + kw;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // ATen rule: take if strictly greater (or NaN); the first valid tap seeds the max
+                    if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
+                }
+                first = false;
+            }
+        }
+        const long long o = ((n * P + p) * (long long)Q + q) * C + cg * 8;
+        store8<T>(y + o, best);
+        if (amax) {
+            uint2 pk;
+            pk.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+            pk.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+            *reinterpret_cast<uint2*>(amax + o) = pk;
+        }
+    }
+}
+
+// Gather form of the backward: each input pixel visits the <=4 windows that contain it and takes
+// dy where the window's recorded argmax is this pixel.  No atomics, no zero-fill pass.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ amax,
+                                                          const T* __restrict__ y, T* __restrict__ dx, int N, int H, int W,
+                                                          int C, int P, int Q) {
+    const int CG = C / 8;
+    const long long total = (long long)N * H * W * CG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        long long t = idx / CG;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long long n = t / H;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        // windows p with 2p-1 <= iy <= 2p+1
+        const int p_lo = iy / 2;                 // floor((iy-1+1)/2)... candidates: (iy+1)/2 and iy/2 when distinct
+        const int p_hi = (iy + 1) / 2;
+        const int q_lo = ix / 2;
+        const int q_hi = (ix + 1) / 2;
+        for (int p = p_lo; p <= p_hi; ++p) {
+            if (p >= P) continue;
+            const int kh = iy - (2 * p - 1);
+            if (kh < 0 || kh > 2) continue;
+            for (int q = q_lo; q <= q_hi; ++q) {
+                if (q >= Q) continue;
+                const int kw = ix - (2 * q - 1);
+                if (kw < 0 || kw > 2) continue;
+                const long long o = ((n * P + p) * (long long)Q + q) * C + cg * 8;
+                const uint2 pk = *reinterpret_cast<const uint2*>(amax + o);
+                float g[8];
+                load8<T>(dy + o, g);
+                if (y) {
+                    float yy[8];
+                    load8<T>(y + o, yy);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+                }
+                const uint32_t want = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                    if (a == want) acc[e] += g[e];
+                }
+            }
+        }
+        store8<T>(dx + ((n * H + iy) * (long long)W + ix) * C + cg * 8, acc);
+    }
+}
+
+// Global avg+max: workgroup = 64 channel-groups x 4 row partitions.
+template <typename T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ feat,
+                                                      int32_t* __restrict__ amax, int HW, int C) {
+    const int CG = C / 8;
+    const int n = blockIdx.y;
+    const int cg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    __shared__ float s_sum[4][64][8];
+    __shared__ float s_max[4][64][8];
+    __shared__ int s_idx[4][64][8];
+    float sum[8], mx[8];
+    int mi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum[e] = 0.f; mx[e] = -INFINITY; mi[e] = 0x7fffffff; }
+    if (cg < CG) {
+        for (int p = part; p < HW; p += 4) {
+            float v[8];
+            load8<T>(x + ((long long)n * HW + p) * C + cg * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sum[e] += v[e];
+                if (mi[e] == 0x7fffffff || v[e] > mx[e] || v[e] != v[e]) { mx[e] = v[e]; mi[e] = p; }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s_sum[part][threadIdx.x & 63][e] = sum[e];
+        s_max[part][threadIdx.x & 63][e] = mx[e];
+        s_idx[part][threadIdx.x & 63][e] = mi[e];
+    }
+    __syncthreads();
+    if (part == 0 && cg < CG) {
+        const int l = threadIdx.x & 63;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = 0.f, m = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int q = 0; q < 4; ++q) {
+                s += s_sum[q][l][e];
+                const float mq = s_max[q][l][e];
+                const int iq = s_idx[q][l][e];
+                if (iq == 0x7fffffff) continue;
+                // first (smallest index) maximum wins ties, matching a sequential strict-> scan
+                if (bi == 0x7fffffff || mq > m || (mq == m && iq < bi)) { m = mq; bi = iq; }
+            }
+            feat[(long long)n * C + cg * 8 + e] = s / (float)HW + m;
+            if (amax) amax[(long long)n * C + cg * 8 + e] = bi;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dfeat, const int32_t* __restrict__ amax,
+                                                      const T* __restrict__ x, T* __restrict__ dx, int N, int HW, int C,
+                                                      int relu_mask) {
+    const int CG = C / 8;
+    const long long total = (long long)N * HW * CG;
+    const float inv = 1.f / (float)HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        const long long t = idx / CG;
+        const int p = (int)(t % HW);
+        const long long n = t / HW;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = dfeat[n * C + cg * 8 + e];
+            v[e] = g * inv + (amax[n * C + cg * 8 + e] == p ? g : 0.f);
+        }
+        const long long o = (n * HW + p) * C + cg * 8;
+        if (relu_mask) {
+            float xx[8];
+            load8<T>(x + o, xx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xx[e] > 0.f ? v[e] : 0.f;
+        }
+        store8<T>(dx + o, v);
+    }
+}
+
+inline int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int cs_maxpool3x3s2_fwd(const void* x, int dtype, void* y, uint8_t* argmax, int N, int H, int W, int C, int P,
+                                   int Q, void* stream) {
+    CS_CHECK_ARG(x && y, "maxpool_fwd: NULL tensor");
+    CS_CHECK_ARG(C > 0 && C % 8 == 0, "maxpool_fwd: C must be a multiple of 8");
+    CS_CHECK_ARG(P == (H + 2 - 3) / 2 + 1 && Q == (W + 2 - 3) / 2 + 1, "maxpool_fwd: P/Q do not match H/W");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)N * P * Q * (C / 8);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, N, H, W, C, P, Q);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, P, Q);
+    else
+        CS_CHECK_ARG(false, "maxpool_fwd: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, const void* y_mask, int dtype, void* dx, int N,
+                                   int H, int W, int C, int P, int Q, void* stream) {
+    CS_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: NULL tensor");
+    CS_CHECK_ARG(C > 0 && C % 8 == 0, "maxpool_bwd: C must be a multiple of 8");
+    CS_CHECK_ARG(P == (H + 2 - 3) / 2 + 1 && Q == (W + 2 - 3) / 2 + 1, "maxpool_bwd: P/Q do not match H/W");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)N * H * W * (C / 8);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)dy, argmax, (const float*)y_mask, (float*)dx, N, H, W, C, P, Q);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (const bf16_t*)y_mask, (bf16_t*)dx, N, H, W, C, P, Q);
+    else
+        CS_CHECK_ARG(false, "maxpool_bwd: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, int N, int HW, int C, void* stream) {
+    CS_CHECK_ARG(x && feat, "gap_fwd: NULL tensor");
+    CS_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad extents");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((C / 8 + 63) / 64, N);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, feat, argmax, HW, C);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, feat, argmax, HW, C);
+    else
+        CS_CHECK_ARG(false, "gap_fwd: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_gap_avgmax_bwd(const float* dfeat, const int32_t* argmax, const void* x, int dtype, void* dx, int N, int HW,
+                                 int C, int relu_mask, void* stream) {
+    CS_CHECK_ARG(dfeat && argmax && dx, "gap_bwd: NULL tensor");
+    CS_CHECK_ARG(!relu_mask || x, "gap_bwd: relu_mask needs x");
+    CS_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_bwd: bad extents");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)N * HW * (C / 8);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, argmax, (const float*)x, (float*)dx, N, HW, C, relu_mask);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, argmax, (const bf16_t*)x, (bf16_t*)dx, N, HW, C, relu_mask);
+    else
+        CS_CHECK_ARG(false, "gap_bwd: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}

@@ -1,0 +1,273 @@
+// Layout / precision staging kernels around the conv family: boundary transposes, BatchNorm
+// folding, weight staging, weight-gradient finalisation, per-channel column sums.
+// All HBM-bound elementwise or small reductions.
+#include "cs_common.h"
+
+namespace {
+
+// ---- NCHW fp32 -> NHWC T (channel padded) : one thread per (pixel, 8 stored channels) ----------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int Cp) {
+    const int groups = Cp / 8 > 0 ? Cp / 8 : 1;
+    const long long total = (long long)N * HW * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int gq = (int)(idx % groups);
+        const long long pix = idx / groups;      // n*HW + p
+        const long long n = pix / HW;
+        const int p = (int)(pix - n * HW);
+        if (Cp % 8 == 0) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = gq * 8 + e;
+                v[e] = c < C ? x[(n * C + c) * HW + p] : 0.f;
+            }
+            store8<T>(y + pix * Cp + gq * 8, v);
+        } else {
+            // Cp == 4 (fp32 stem input)
+            for (int c = 0; c < Cp; ++c) y[pix * Cp + c] = from_f32<T>(c < C ? x[(n * C + c) * HW + p] : 0.f);
+        }
+    }
+}
+
+// ---- NHWC T -> NCHW fp32: LDS-free, reads 8 channels per thread, writes are strided by HW but
+// consecutive threads take consecutive pixels so each channel plane gets coalesced stores. -------
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ y, float* __restrict__ x, int N, int C, int HW, int Cp) {
+    const int groups = (C + 7) / 8;
+    const long long total = (long long)N * HW * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx % ((long long)N * HW);
+        const int gq = (int)(idx / ((long long)N * HW));
+        const long long n = pix / HW;
+        const int p = (int)(pix - n * HW);
+        for (int e = 0; e < 8; ++e) {
+            const int c = gq * 8 + e;
+            if (c < C) x[(n * C + c) * HW + p] = to_f32<T>(y[pix * Cp + c]);
+        }
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, float* rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    // same operation order as ATen's eval batch_norm: invstd = 1/sqrt(var+eps)
+    const float r = 1.0f / sqrtf(var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    const float s = g * r;
+    if (scale) scale[c] = s;
+    if (shift) shift[c] = b - mean[c] * s;
+    if (rstd) rstd[c] = r;
+}
+
+// ---- weights: fp32 [K][Cin][R][S] (x scale[k]) -> T [K][R][S][Cp] and/or T [Cin][R][S][Kp] ------
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale, int K, int Cin, int R,
+                                   int S, int Cp, int Kp, T* __restrict__ w_khwc, T* __restrict__ w_chwk) {
+    const int RS = R * S;
+    if (w_khwc) {
+        const long long total = (long long)K * RS * Cp;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+             idx += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(idx % Cp);
+            const int rs = (int)((idx / Cp) % RS);
+            const int k = (int)(idx / ((long long)Cp * RS));
+            float v = 0.f;
+            if (c < Cin) {
+                v = w[((long long)k * Cin + c) * RS + rs];
+                if (scale) v *= scale[k];
+            }
+            w_khwc[idx] = from_f32<T>(v);
+        }
+    }
+    if (w_chwk) {
+        const long long total = (long long)Cin * RS * Kp;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+             idx += (long long)gridDim.x * blockDim.x) {
+            const int k = (int)(idx % Kp);
+            const int rs = (int)((idx / Kp) % RS);
+            const int c = (int)(idx / ((long long)Kp * RS));
+            float v = 0.f;
+            if (k < K) {
+                v = w[((long long)k * Cin + c) * RS + rs];
+                if (scale) v *= scale[k];
+            }
+            w_chwk[idx] = from_f32<T>(v);
+        }
+    }
+}
+
+// ---- wgrad finalize: one workgroup per output channel k --------------------------------------
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ dw_khwc, const float* __restrict__ w,
+                                                             const float* scale, const float* rstd, const float* mean,
+                                                             const float* gsum, int Cin, int R, int S, int Cp,
+                                                             float* __restrict__ dw, float* dbias, float* dgamma,
+                                                             float* dbeta, int accumulate) {
+    const int k = blockIdx.x;
+    const int RS = R * S;
+    const int per = Cin * RS;
+    const float sc = scale ? scale[k] : 1.f;
+    float dot = 0.f;
+    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+        const int c = j / RS;
+        const int rs = j - c * RS;
+        const float raw = dw_khwc[((long long)k * RS + rs) * Cp + c];
+        const long long o = (long long)k * per + j;
+        if (dgamma) dot += w[o] * raw;
+        const float val = sc * raw;
+        dw[o] = accumulate ? dw[o] + val : val;
+    }
+    if (dgamma || dbeta || dbias) {
+        __shared__ float red[4];
+        dot = wave_sum(dot);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = red[0] + red[1] + red[2] + red[3];
+            const float gs = gsum ? gsum[k] : 0.f;
+            if (dgamma) {
+                const float v = rstd[k] * (tot - mean[k] * gs);
+                dgamma[k] = accumulate ? dgamma[k] + v : v;
+            }
+            if (dbeta) dbeta[k] = accumulate ? dbeta[k] + gs : gs;
+            if (dbias) dbias[k] = accumulate ? dbias[k] + gs : gs;
+        }
+    }
+}
+
+// ---- column sums: out[c] += sum_m g[m][c].  Thread owns 8 channels, block owns a row slab. -----
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, long long M, int C, float* __restrict__ out,
+                                                     int rows_per_block) {
+    const int CG = C / 8;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    // thread t handles channel group (t % CG') over rows stepping by (256 / CG') when CG <= 256
+    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;   // groups handled this pass
+        // largest power-of-two row parallelism
+        int rpar = 256 / width;
+        if (rpar < 1) rpar = 1;
+        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int rr = threadIdx.x / width;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (rr < rpar) {
+            for (long long r = r0 + rr; r < r1; r += rpar) {
+                float v[8];
+                load8<T>(g + r * C + cg * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(out + cg * 8 + e, acc[e]);
+        }
+    }
+}
+
+}  // namespace
+
+static inline int grid_for(long long total, int block) {
+    long long b = (total + block - 1) / block;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int cs_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream) {
+    CS_CHECK_ARG(x && y, "nchw_to_nhwc: NULL tensor");
+    CS_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_nhwc: bad extents");
+    CS_CHECK_ARG(Cp % 8 == 0 || (dtype == CS_F32 && Cp == 4), "nchw_to_nhwc: Cp must be a multiple of 8 (or 4 for fp32)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int groups = Cp / 8 > 0 ? Cp / 8 : 1;
+    const long long total = (long long)N * H * W * groups;
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, x, (float*)y, N, C, H * W, Cp);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, x, (bf16_t*)y, N, C, H * W, Cp);
+    else
+        CS_CHECK_ARG(false, "nchw_to_nhwc: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_nhwc_to_nchw(const void* y, int dtype, float* x, int N, int C, int H, int W, int Cp, void* stream) {
+    CS_CHECK_ARG(x && y, "nhwc_to_nchw: NULL tensor");
+    CS_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nhwc_to_nchw: bad extents");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)N * H * W * ((C + 7) / 8);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const float*)y, x, N, C, H * W, Cp);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)y, x, N, C, H * W, Cp);
+    else
+        CS_CHECK_ARG(false, "nhwc_to_nchw: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* shift, float* rstd, int C, void* stream) {
+    CS_CHECK_ARG(mean && var && C > 0, "bn_fold: NULL statistics");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, scale, shift, rstd, C);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int K, int Cin, int R, int S, int Cp, int Kp,
+                              void* w_khwc, void* w_chwk, void* stream) {
+    CS_CHECK_ARG(w && (w_khwc || w_chwk), "weight_prep: NULL tensor");
+    CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "weight_prep: bad extents");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long t1 = (long long)K * R * S * Cp, t2 = (long long)Cin * R * S * Kp;
+    const long long total = t1 > t2 ? t1 : t2;
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, scale, K, Cin, R, S, Cp, Kp,
+                           (float*)w_khwc, (float*)w_chwk);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, scale, K, Cin, R, S, Cp, Kp,
+                           (bf16_t*)w_khwc, (bf16_t*)w_chwk);
+    else
+        CS_CHECK_ARG(false, "weight_prep: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, const float* rstd,
+                                 const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp, float* dw,
+                                 float* dbias, float* dgamma, float* dbeta, int accumulate, void* stream) {
+    CS_CHECK_ARG(dw_khwc && dw, "wgrad_finalize: NULL tensor");
+    CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin, "wgrad_finalize: bad extents");
+    CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum), "wgrad_finalize: dgamma needs w, rstd, mean, gsum");
+    CS_CHECK_ARG(!(dbeta || dbias) || gsum, "wgrad_finalize: dbeta/dbias need gsum");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(K), dim3(256), 0, st, dw_khwc, w, scale, rstd, mean, gsum, Cin, R, S, Cp, dw,
+                       dbias, dgamma, dbeta, accumulate);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream) {
+    CS_CHECK_ARG(g && out, "colsum: NULL tensor");
+    CS_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "colsum: C must be a positive multiple of 8");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // ~2048 blocks, at least 64 rows each
+    long long rows = (M + 2047) / 2048;
+    if (rows < 64) rows = 64;
+    const int blocks = (int)((M + rows - 1) / rows);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, M, C, out, (int)rows);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, M, C, out, (int)rows);
+    else
+        CS_CHECK_ARG(false, "colsum: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}

@@ -1,0 +1,216 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).
+
+Every function checks that its operands live on the GPU and are contiguous, then enqueues the HIP
+kernel on torch's current stream.  Activations are NHWC tensors of dtype float32 (parity mode) or
+bfloat16 (throughput mode) whose channel count is already padded (see ``pad_channels``).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU, CS_BF16, CS_F32, CsConvGeom  # noqa: F401
+
+
+def _code(dtype):
+    if dtype == torch.float32:
+        return CS_F32
+    if dtype == torch.bfloat16:
+        return CS_BF16
+    raise TypeError(f"unsupported activation dtype {dtype}; use torch.float32 or torch.bfloat16")
+
+
+def chunk(dtype):
+    """Elements per 16-byte chunk."""
+    return 4 if dtype == torch.float32 else 8
+
+
+def pad_channels(c, dtype=None):
+    """Stored channel count: multiple of 8 (a multiple of both chunk sizes)."""
+    return (c + 7) // 8 * 8
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("cellsegmentation_amd kernels need GPU tensors: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("cellsegmentation_amd kernels need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_geom(N, H, W, C, K, R, S, stride, pad):
+    P = (H + 2 * pad - R) // stride + 1
+    Q = (W + 2 * pad - S) // stride + 1
+    return CsConvGeom(N, H, W, C, K, R, S, stride, pad, P, Q)
+
+
+# ---------------------------------------------------------------- layout
+def to_nhwc(x, dtype, Cp):
+    """x[N,C,H,W] fp32 -> [N,H,W,Cp] dtype (zero padded channels)."""
+    N, C, H, W = x.shape
+    if x.dtype != torch.float32:
+        raise TypeError("to_nhwc expects an fp32 NCHW tensor")
+    y = torch.empty((N, H, W, Cp), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().cs_nchw_to_nhwc(_p(x), _p(y), _code(dtype), N, C, H, W, Cp, _stream()), "nchw_to_nhwc")
+    return y
+
+
+def to_nchw(y, C):
+    """y[N,H,W,Cp] -> [N,C,H,W] fp32 (first C channels)."""
+    N, H, W, Cp = y.shape
+    x = torch.empty((N, C, H, W), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.load().cs_nhwc_to_nchw(_p(y), _code(y.dtype), _p(x), N, C, H, W, Cp, _stream()), "nhwc_to_nchw")
+    return x
+
+
+# ---------------------------------------------------------------- parameters
+def bn_fold(gamma, beta, mean, var, eps):
+    C = mean.numel()
+    out = torch.empty((3, C), dtype=torch.float32, device=mean.device)
+    _lib.check(_lib.load().cs_bn_fold(_p(gamma), _p(beta), _p(mean), _p(var), eps, _p(out[0]), _p(out[1]), _p(out[2]), C,
+                                      _stream()), "bn_fold")
+    return out[0], out[1], out[2]
+
+
+def weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=False):
+    K, Cin, R, S = w.shape
+    w_khwc = torch.empty((K, R, S, Cp), dtype=dtype, device=w.device) if want_fwd else None
+    w_chwk = torch.empty((Cin, R, S, Kp), dtype=dtype, device=w.device) if want_bwd else None
+    _lib.check(_lib.load().cs_weight_prep(_p(w), _p(scale), _code(dtype), K, Cin, R, S, Cp, Kp, _p(w_khwc), _p(w_chwk),
+                                          _stream()), "weight_prep")
+    return w_khwc, w_chwk
+
+
+# ---------------------------------------------------------------- convolution family
+def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None):
+    y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().cs_conv2d_fwd(ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift),
+                                         _p(residual), act, _p(y), _p(stats), _stream()), "conv2d_fwd")
+    return y
+
+
+def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None):
+    dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().cs_conv2d_dgrad(ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask),
+                                           _p(dx), _p(colsum), _stream()), "conv2d_dgrad")
+    return dx
+
+
+def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True):
+    """dw_raw[K,R,S,Cp] fp32 (pre-zeroed) += wgrad."""
+    _lib.check(_lib.load().cs_conv2d_wgrad(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw_raw),
+                                           1 if use_tr_read else 0, _stream()), "conv2d_wgrad")
+    return dw_raw
+
+
+def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False):
+    K, R, S, Cp = dw_raw.shape
+    _lib.check(_lib.load().cs_wgrad_finalize(_p(dw_raw), _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K, Cin, R, S, Cp,
+                                             _p(dw), _p(dbias), _p(dgamma), _p(dbeta), 1 if accumulate else 0, _stream()),
+               "wgrad_finalize")
+
+
+def colsum(g, out=None):
+    C = g.shape[-1]
+    M = g.numel() // C
+    if out is None:
+        out = torch.zeros((C,), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.load().cs_colsum(_p(g), _code(g.dtype), M, C, _p(out), _stream()), "colsum")
+    return out
+
+
+# ---------------------------------------------------------------- pooling
+def maxpool_fwd(x, want_argmax=True):
+    N, H, W, C = x.shape
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, P, Q, C), dtype=x.dtype, device=x.device)
+    am = torch.empty((N, P, Q, C), dtype=torch.uint8, device=x.device) if want_argmax else None
+    _lib.check(_lib.load().cs_maxpool3x3s2_fwd(_p(x), _code(x.dtype), _p(y), _p(am), N, H, W, C, P, Q, _stream()), "maxpool_fwd")
+    return y, am
+
+
+def maxpool_bwd(dy, argmax, y_mask, in_hw):
+    N, P, Q, C = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().cs_maxpool3x3s2_bwd(_p(dy), _p(argmax), _p(y_mask), _code(dy.dtype), _p(dx), N, H, W, C, P, Q,
+                                               _stream()), "maxpool_bwd")
+    return dx
+
+
+def gap_fwd(x):
+    N, H, W, C = x.shape
+    feat = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    am = torch.empty((N, C), dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().cs_gap_avgmax_fwd(_p(x), _code(x.dtype), _p(feat), _p(am), N, H * W, C, _stream()), "gap_fwd")
+    return feat, am
+
+
+def gap_bwd(dfeat, argmax, x, relu_mask):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().cs_gap_avgmax_bwd(_p(dfeat), _p(argmax), _p(x), _code(x.dtype), _p(dx), N, H * W, C,
+                                             1 if relu_mask else 0, _stream()), "gap_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------- heads / losses
+def linear_fwd(x, w, b, act=CS_ACT_NONE):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cs_linear_fwd(_p(x), _p(w), _p(b), _p(y), M, N, K, act, _stream()), "linear_fwd")
+    return y
+
+
+def linear_bwd(x, w, dy, y=None, act=CS_ACT_NONE, need_dx=True, need_dw=True, need_db=True):
+    M, K = x.shape
+    N = w.shape[0]
+    dx = torch.empty((M, K), dtype=torch.float32, device=x.device) if need_dx else None
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device) if (need_dw or need_db) else None
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
+    _lib.check(_lib.load().cs_linear_bwd(_p(x), _p(w), _p(dy), _p(y), act, _p(dx), _p(dw), _p(db), M, N, K, 0, _stream()),
+               "linear_bwd")
+    return dx, dw, db
+
+
+def softmax_ce(logits, labels, gamma=1.0, want_grad=True):
+    M, C = logits.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    _lib.check(_lib.load().cs_softmax_ce(_p(logits), _p(labels), float(gamma), _p(loss), _p(dl), M, C, _stream()), "softmax_ce")
+    return loss, dl
+
+
+def softmax_prob1(logits):
+    M, C = logits.shape
+    p1 = torch.empty((M,), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().cs_softmax_prob1(_p(logits), _p(p1), M, C, _stream()), "softmax_prob1")
+    return p1
+
+
+def mse(x, t, weighted=False, mean=True, want_grad=True):
+    M = x.numel()
+    loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if want_grad else None
+    _lib.check(_lib.load().cs_mse(_p(x), _p(t), 1 if weighted else 0, 1 if mean else 0, _p(loss), _p(dx), M, _stream()), "mse")
+    return loss, dx
+
+
+def segmented_topk(probs, groups, k_per_tile, seg_offsets, max_run):
+    """Device-side order[index] of inference.py:31-43. Returns (out_idx[T] int64, count[1] int64)."""
+    T = probs.numel()
+    lib = _lib.load()
+    ws_bytes = lib.cs_segmented_topk_workspace(T)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=probs.device)
+    out = torch.empty((T,), dtype=torch.int64, device=probs.device)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=probs.device)
+    _lib.check(lib.cs_segmented_topk(_p(probs), _p(groups), _p(k_per_tile), _p(seg_offsets), seg_offsets.numel() - 1,
+                                     int(max_run), T, _p(out), _p(cnt), _p(ws), ws_bytes, _stream()), "segmented_topk")
+    return out, cnt

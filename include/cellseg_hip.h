@@ -1,0 +1,142 @@
+/* cellseg_hip.h -- C ABI of libcellseg_hip.so, the MI355X (gfx950) kernel library behind the
+ * per-tile CNN hot path of Newiz430/CellSegmentation.
+ *
+ * The reference has no FFI: its hot path is Python calling torch.nn modules (model/resnet.py,
+ * model/resnext.py, model/efficientnet.py, train/train.py, train/losses.py, metrics/metrics.py,
+ * inference.py).  Each entry point below replaces the ATen op(s) that a cited reference line
+ * dispatches; the Python host mirror in cellsegmentation_amd/ binds them with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *  - activations are NHWC, dtype CS_F32 (parity mode, exact-f32 MFMA) or CS_BF16 (throughput
+ *    mode, fp32 accumulate); channel counts are multiples of the 16-byte chunk
+ *    (4 for CS_F32, 8 for CS_BF16); parameters/gradients/statistics are fp32 (torch layouts);
+ *  - nothing allocates, frees or synchronises: work is enqueued on `stream` (a hipStream_t
+ *    passed as void*); workspaces are caller-owned;
+ *  - return value: CS_OK or a negative CS_ERR_*; cs_last_error() gives the message.
+ */
+#ifndef CELLSEG_HIP_H_
+#define CELLSEG_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CS_F32 = 0, CS_BF16 = 1 };
+enum { CS_OK = 0, CS_ERR_INVALID_ARG = -1, CS_ERR_LAUNCH = -2, CS_ERR_UNSUPPORTED = -3 };
+enum { CS_ACT_NONE = 0, CS_ACT_RELU = 1, CS_ACT_SILU = 2 };
+
+int cs_abi_version(void);
+const char* cs_last_error(void);
+
+/* Geometry of one 2-D convolution (torch.nn.Conv2d as used at model/resnet.py:20,23,51,53,55,
+ * 111,183,198,164).  Input N x H x W x C (C = stored/padded channels), output N x P x Q x K. */
+typedef struct CsConvGeom {
+    int32_t N, H, W, C;
+    int32_t K;
+    int32_t R, S;       /* kernel height, width */
+    int32_t stride, pad;
+    int32_t P, Q;       /* output height, width */
+} CsConvGeom;
+
+/* ---- layout / precision changes at the module boundary ------------------------------------- */
+/* x[N][C][H][W] fp32 (the reference's input layout, dataset/dataset.py:78-83 output) ->
+ * y[N][H][W][Cp] dtype, channels C..Cp-1 zero-filled. */
+int cs_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream);
+/* y[N][H][W][Cp] dtype -> x[N][C][H][W] fp32 (first C channels).  Used for segmentation logits
+ * (model/resnet.py:301-303) and to hand gradients back in torch layout. */
+int cs_nhwc_to_nchw(const void* y, int dtype, float* x, int N, int C, int H, int W, int Cp, void* stream);
+
+/* ---- BatchNorm2d in eval mode folded to per-channel scale/shift (resnet.py:254-258: the
+ * freeze_bn path runs every BN with running statistics) --------------------------------------
+ * scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, rstd = rsqrt(var+eps). */
+int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+               float* scale, float* shift, float* rstd, int C, void* stream);
+
+/* ---- weight staging -------------------------------------------------------------------------
+ * w[K][Cin][R][S] fp32 (torch Conv2d.weight) times optional per-K `scale` ->
+ *   w_khwc [K ][R][S][Cp]  (forward operand, Cp = padded Cin)      if non-NULL
+ *   w_chwk [Cin_rows][R][S][Kp] (dgrad operand, Kp = padded K)      if non-NULL
+ * Cin_rows = number of rows written in w_chwk (== Cin, must already be a chunk multiple). */
+int cs_weight_prep(const float* w, const float* scale, int dtype, int K, int Cin, int R, int S, int Cp, int Kp,
+                   void* w_khwc, void* w_chwk, void* stream);
+
+/* ---- convolution family (implicit GEMM on MFMA) ---------------------------------------------
+ * forward: y = act( scale[k]*conv(x,w) + shift[k] + residual ), any of scale/shift/residual NULL.
+ *   Fuses Conv2d+BatchNorm2d(eval)+ReLU(+residual add) of BasicBlock/Bottleneck.forward
+ *   (resnet.py:28-43, 60-78) and Conv2d(bias) of upsample_conv/seg_out_conv (resnet.py:195-200,164).
+ *   stats (nullable, fp64 [2][K]): accumulates sum and sum of squares of the STORED output per channel
+ *   (BatchNorm2d train-mode batch statistics). */
+int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
+                  const float* shift, const void* residual, int act, void* y, double* stats, void* stream);
+/* data gradient: dx = ( conv_transpose(dy, w) + add ) * [mask > 0]; add/mask nullable, both shaped like x.
+ *   `mask` is the conv's own input activation when that input came out of a ReLU (the ReLU backward of
+ *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */
+int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
+                    const void* mask, void* dx, float* colsum, void* stream);
+/* weight gradient, raw: dw_khwc[K][R][S][Cp] fp32 += sum over pixels dy (x) im2col(x).
+ *   The caller zeroes dw_khwc first; split-K partial sums are combined with fp32 atomics. */
+int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
+                    int use_tr_read, void* stream);
+/* dw[K][Cin][R][S] (torch layout, ACCUMULATED into when accumulate!=0) = scale[k]*dw_khwc[k][r][s][c];
+ * and, when dgamma/dbeta non-NULL, the eval-mode BatchNorm parameter gradients
+ *   dbeta[k] = gsum[k];  dgamma[k] = rstd[k]*( sum_j w[k][j]*dw_raw[k][j] - mean[k]*gsum[k] ). */
+int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, const float* rstd,
+                      const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp,
+                      float* dw, float* dbias, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* per-channel column sums: out[c] (+)= sum_m g[m][c]; fp32 out, zeroed by the caller. */
+int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream);
+
+/* ---- pooling --------------------------------------------------------------------------------
+ * MaxPool2d(3, stride 2, pad 1) (resnet.py:114). */
+/* argmax (nullable, uint8 [N][P][Q][C]): window tap kh*3+kw of the first maximum in scan order
+ * (ATen's max_pool2d_with_indices tie rule: strictly-greater replaces). */
+int cs_maxpool3x3s2_fwd(const void* x, int dtype, void* y, uint8_t* argmax, int N, int H, int W, int C, int P, int Q,
+                        void* stream);
+/* dx[n][iy][ix][c] = sum over the <=4 windows containing (iy,ix) whose argmax is this pixel of
+ * dy * [y_mask > 0] (y_mask nullable: the pooled output when a ReLU precedes the pool and the
+ * caller wants the ReLU backward of resnet.py:113 fused). Gather form: no atomics. */
+int cs_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, const void* y_mask, int dtype, void* dx, int N, int H,
+                        int W, int C, int P, int Q, void* stream);
+/* AdaptiveAvgPool2d(1)+AdaptiveMaxPool2d(1) summed (resnet.py:266,274): feat[N][C] fp32,
+ * argmax[N][C] int32 = first spatial index of the maximum. */
+int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, int N, int HW, int C, void* stream);
+/* dx[n][p][c] = ( dfeat[n][c]/HW + (p==argmax[n][c]) * dfeat[n][c] ) * [x>0 if relu_mask]. */
+int cs_gap_avgmax_bwd(const float* dfeat, const int32_t* argmax, const void* x, int dtype, void* dx, int N, int HW,
+                      int C, int relu_mask, void* stream);
+
+/* ---- heads: Linear (resnet.py:126,137,140,150), losses (train/train.py:34,80-83) ------------- */
+/* y[M][N] = x[M][K] @ w[N][K]^T + b[N]  (fp32; b nullable; act applied last) */
+int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act, void* stream);
+/* dx[M][K] = dy @ w (nullable dx); dw[N][K] (+)= dy^T @ x; db[N] (+)= colsum(dy).  dy is first
+ * multiplied by [y>0] when act==CS_ACT_RELU (y required then). */
+int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
+                  float* db, int M, int N, int K, int accumulate, void* stream);
+/* CrossEntropyLoss(mean) * gamma on logits[M][C]; loss: 1 fp32 (overwritten); dlogits nullable. */
+int cs_softmax_ce(const float* logits, const int64_t* labels, float gamma, float* loss, float* dlogits, int M, int C,
+                  void* stream);
+/* softmax(logits,1)[:,1] (inference.py:24-27) */
+int cs_softmax_prob1(const float* logits, float* p1, int M, int C, void* stream);
+/* sum or mean of w_i*(x_i-t_i)^2, w_i = 1 (weighted==0) or the reference's weighted_mse weights
+ * (metrics/metrics.py:23-33: ln(t) if t>=20 else t).  dx nullable. scale = upstream grad factor. */
+int cs_mse(const float* x, const float* t, int weighted, int mean, float* loss, float* dx, int M, void* stream);
+
+/* ---- adaptive top-k instance selection (inference.py:31-43) ---------------------------------
+ * probs[T] fp32, groups[T] int32 non-decreasing, k_per_tile[T] int32 (k of the tile's group).
+ * seg_offsets[n_groups+1] int64 (device): start of each group's run; max_run = longest run (host int).
+ * Writes the reference's order[index] list: out_idx[0..*out_count) int64 (device), reproducing
+ * np.lexsort((probs, groups)) + the wrap-around (i+k)%T comparison bit-exactly.
+ * workspace: >= cs_segmented_topk_workspace(T) bytes. */
+size_t cs_segmented_topk_workspace(long long T);
+int cs_segmented_topk(const float* probs, const int32_t* groups, const int32_t* k_per_tile,
+                      const int64_t* seg_offsets, int n_groups, int max_run, long long T, int64_t* out_idx,
+                      int64_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELLSEG_HIP_H_ */

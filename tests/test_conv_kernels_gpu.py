@@ -1,0 +1,156 @@
+"""GPU parity of the implicit-GEMM convolution family (fwd / dgrad / wgrad) through the C ABI,
+against torch's CPU fp32 conv on the same inputs.
+
+Tolerances: fp32 mode 2e-5 relative to max|ref| (exact-f32 MFMA, different summation order);
+bf16 mode: inputs are pre-rounded to bf16 so the only differences are fp32 accumulation order and
+the final bf16 rounding of the stored result: 1e-2 relative to max|ref|.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import kernels as K  # noqa: E402
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+
+#        N   H   W  Cin Cout R  s  p
+SHAPES = [
+    (2, 19, 19, 64, 256, 1, 1, 0),
+    (2, 19, 19, 64, 128, 1, 2, 0),
+    (2, 19, 19, 64, 64, 3, 1, 1),
+    (3, 10, 10, 128, 128, 3, 1, 1),
+    (2, 19, 19, 64, 128, 3, 2, 1),
+    (2, 37, 37, 3, 64, 7, 2, 3),
+    (2, 13, 13, 24, 40, 3, 1, 1),
+    (2, 11, 11, 40, 24, 5, 2, 2),
+    (8, 80, 80, 32, 128, 1, 1, 0),    # M=51200: 128x128 tile path
+    (8, 80, 80, 16, 64, 3, 1, 1),     # 128x64 tile path
+]
+
+
+def _q(t, dtype):
+    return t.to(dtype).float()
+
+
+def _nhwc(t_nchw, dtype, dev, Cp=None):
+    n, c, h, w = t_nchw.shape
+    Cp = Cp or K.pad_channels(c)
+    out = torch.zeros((n, h, w, Cp), dtype=dtype)
+    out[..., :c] = t_nchw.permute(0, 2, 3, 1).to(dtype)
+    return out.to(dev)
+
+
+def _from_nhwc(t, c):
+    return t[..., :c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_fwd_dgrad_wgrad(shape, dtype, dev):
+    N, H, W, Cin, Cout, R, s, p = shape
+    g = torch.Generator().manual_seed(1234 + Cin * 7 + Cout)
+    x = _q(torch.randn((N, Cin, H, W), generator=g), dtype)
+    w = _q(torch.randn((Cout, Cin, R, R), generator=g) / (Cin * R * R) ** 0.5, dtype)
+    scale = torch.rand((Cout,), generator=g) + 0.5
+    shift = torch.randn((Cout,), generator=g) * 0.1
+    Cp, Kp = K.pad_channels(Cin), K.pad_channels(Cout)
+    geom = K.make_geom(N, H, W, Cp, Kp, R, R, s, p)
+    P, Q = geom.P, geom.Q
+    res = _q(torch.randn((N, Cout, P, Q), generator=g), dtype)
+
+    # ---------- forward: relu(scale*conv + shift + res)
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    ref_full = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    xd = _nhwc(x, dtype, dev)
+    w_khwc, w_chwk = K.weight_prep(w.to(dev), None, dtype, Cp, Kp, want_fwd=True, want_bwd=True)
+    sc = torch.ones(Kp); sc[:Cout] = scale
+    sh = torch.zeros(Kp); sh[:Cout] = shift
+    # padded output channels: the weight rows beyond Cout do not exist -> allocate padded weights
+    if Kp != Cout:
+        wk = torch.zeros((Kp,) + tuple(w_khwc.shape[1:]), dtype=dtype, device=dev)
+        wk[:Cout] = w_khwc
+        w_khwc = wk
+    y_plain = K.conv_fwd(geom, xd, w_khwc)
+    y_full = K.conv_fwd(geom, xd, w_khwc, sc.to(dev), sh.to(dev), _nhwc(res, dtype, dev, Kp), K.CS_ACT_RELU)
+    torch.cuda.synchronize()
+    e1 = _relerr(_from_nhwc(y_plain, Cout), ref)
+    e2 = _relerr(_from_nhwc(y_full, Cout), ref_full)
+    assert e1 < TOL[dtype], f"fwd plain relerr {e1}"
+    assert e2 < TOL[dtype], f"fwd fused relerr {e2}"
+    if Kp != Cout:
+        assert float(y_plain[..., Cout:].float().abs().max()) == 0.0
+
+    # ---------- dgrad (needs Cin chunk-aligned rows in w_chwk)
+    dy = _q(torch.randn((N, Cout, P, Q), generator=g), dtype)
+    dyd = _nhwc(dy, dtype, dev, Kp)
+    if Cin % 8 == 0:
+        ref_dx = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, stride=s, padding=p)
+        add = _q(torch.randn((N, Cin, H, W), generator=g), dtype)
+        mask = _q(torch.randn((N, Cin, H, W), generator=g), dtype)
+        ref_dx2 = (ref_dx + add) * (mask > 0)
+        dx = K.conv_dgrad(geom, dyd, w_chwk)
+        cs = torch.zeros((Cp,), dtype=torch.float32, device=dev)
+        dx2 = K.conv_dgrad(geom, dyd, w_chwk, _nhwc(add, dtype, dev), _nhwc(mask, dtype, dev), cs)
+        torch.cuda.synchronize()
+        e3 = _relerr(_from_nhwc(dx, Cin), ref_dx)
+        e4 = _relerr(_from_nhwc(dx2, Cin), ref_dx2)
+        assert e3 < TOL[dtype], f"dgrad relerr {e3}"
+        assert e4 < TOL[dtype], f"dgrad fused relerr {e4}"
+        ref_cs = dx2[..., :Cin].float().sum(dim=(0, 1, 2)).cpu()
+        e5 = _relerr(cs[:Cin].cpu(), ref_cs)
+        assert e5 < 1e-3, f"dgrad colsum relerr {e5}"
+
+    # ---------- wgrad (both LDS operand paths for bf16)
+    ref_dw = torch.nn.grad.conv2d_weight(x, (Cout, Cin, R, R), dy, stride=s, padding=p)
+    for use_tr in ([False, True] if dtype == torch.bfloat16 else [False]):
+        raw = torch.zeros((Kp, R, R, Cp), dtype=torch.float32, device=dev)
+        K.conv_wgrad(geom, xd, dyd, raw, use_tr_read=use_tr)
+        dw = torch.empty((Cout, Cin, R, R), dtype=torch.float32, device=dev)
+        gsum = K.colsum(dyd)
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        K.wgrad_finalize(raw[:Cout].contiguous(), None, None, None, None, gsum, Cin, dw, dbias=dbias)
+        torch.cuda.synchronize()
+        e6 = _relerr(dw.cpu(), ref_dw)
+        assert e6 < (1e-4 if dtype == torch.float32 else 2e-3), f"wgrad(tr={use_tr}) relerr {e6}"
+        e7 = _relerr(dbias.cpu(), dy.sum(dim=(0, 2, 3)))
+        assert e7 < 1e-4, f"colsum/dbias relerr {e7}"
+
+
+def test_bn_fold_and_finalize_bn_grads(dev):
+    """eval-BN folded conv: dgamma/dbeta from the raw weight gradient (no saved conv output)."""
+    torch.manual_seed(7)
+    N, C, Kc, H = 2, 16, 24, 9
+    x = torch.randn(N, C, H, H)
+    w = torch.randn(Kc, C, 3, 3, requires_grad=True)
+    gamma = (torch.rand(Kc) + 0.5).requires_grad_()
+    beta = torch.randn(Kc).requires_grad_()
+    mean, var, eps = torch.randn(Kc) * 0.1, torch.rand(Kc) + 0.5, 1e-5
+    z = F.conv2d(x, w, padding=1)
+    u = F.batch_norm(z, mean, var, gamma, beta, False, 0.0, eps)
+    g = torch.randn_like(u)
+    u.backward(g)
+    scale, shift, rstd = K.bn_fold(gamma.detach().to(dev), beta.detach().to(dev), mean.to(dev), var.to(dev), eps)
+    torch.cuda.synchronize()
+    ref_scale = gamma.detach() / torch.sqrt(var + eps)
+    assert _relerr(scale.cpu(), ref_scale) < 1e-6
+    assert _relerr(shift.cpu(), beta.detach() - mean * ref_scale) < 1e-6
+    geom = K.make_geom(N, H, H, C, Kc, 3, 3, 1, 1)
+    xd = _nhwc(x, torch.float32, dev)
+    gd = _nhwc(g, torch.float32, dev)
+    raw = torch.zeros((Kc, 3, 3, C), dtype=torch.float32, device=dev)
+    K.conv_wgrad(geom, xd, gd, raw)
+    gsum = K.colsum(gd)
+    dw = torch.empty((Kc, C, 3, 3), device=dev)
+    dgamma = torch.empty((Kc,), device=dev)
+    dbeta = torch.empty((Kc,), device=dev)
+    K.wgrad_finalize(raw, w.detach().to(dev), scale, rstd, mean.to(dev), gsum, C, dw, dgamma=dgamma, dbeta=dbeta)
+    torch.cuda.synchronize()
+    assert _relerr(dw.cpu(), w.grad) < 1e-4
+    assert _relerr(dgamma.cpu(), gamma.grad) < 1e-4
+    assert _relerr(dbeta.cpu(), beta.grad) < 1e-4

@@ -1,0 +1,163 @@
+"""GPU parity of pooling, heads/losses and the adaptive top-k kernel through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import kernels as K  # noqa: E402
+
+
+def _nhwc(t, dtype, dev):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+
+
+def _nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(10, 10), (15, 14), (7, 9)])
+def test_maxpool(dtype, hw, dev):
+    torch.manual_seed(3)
+    H, W = hw
+    x = torch.randn(2, 16, H, W).to(dtype).float()
+    x = torch.relu(x)                      # plenty of exact ties at 0, like the stem output
+    x.requires_grad_()
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn_like(y).to(dtype).float()
+    y.backward(dy)
+    yd, am = K.maxpool_fwd(_nhwc(x.detach(), dtype, dev))
+    dxd = K.maxpool_bwd(_nhwc(dy, dtype, dev), am, None, (H, W))
+    torch.cuda.synchronize()
+    assert torch.equal(_nchw(yd), y.detach())
+    ref = x.grad.to(dtype).float()
+    assert float((_nchw(dxd) - ref).abs().max()) <= (1e-6 if dtype == torch.float32 else 4e-2)
+    # fused ReLU mask: identical to masking dy by [y>0] first
+    dxm = K.maxpool_bwd(_nhwc(dy, dtype, dev), am, yd, (H, W))
+    x2 = x.detach().clone().requires_grad_()
+    F.max_pool2d(x2, 3, 2, 1).backward(dy * (y.detach() > 0))
+    torch.cuda.synchronize()
+    assert float((_nchw(dxm) - x2.grad.to(dtype).float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 4e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gap_avgmax(dtype, dev):
+    torch.manual_seed(5)
+    x = torch.relu(torch.randn(3, 72, 10, 10)).to(dtype).float().requires_grad_()
+    f = (F.adaptive_avg_pool2d(x, 1) + F.adaptive_max_pool2d(x, 1)).flatten(1)
+    df = torch.randn_like(f)
+    f.backward(df)
+    xd = _nhwc(x.detach(), dtype, dev)
+    feat, am = K.gap_fwd(xd)
+    dx = K.gap_bwd(df.to(dev), am, xd, relu_mask=False)
+    dxm = K.gap_bwd(df.to(dev), am, xd, relu_mask=True)
+    torch.cuda.synchronize()
+    assert float((feat.cpu() - f.detach()).abs().max()) < 1e-5
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert float((_nchw(dx) - x.grad).abs().max()) < tol
+    assert float((_nchw(dxm) - x.grad * (x.detach() > 0)).abs().max()) < tol
+
+
+def test_linear_ce_mse(dev):
+    torch.manual_seed(11)
+    M, Kf, N = 9, 515, 7
+    x = torch.randn(M, Kf, requires_grad=True)
+    w = torch.randn(N, Kf, requires_grad=True)
+    b = torch.randn(N, requires_grad=True)
+    lab = torch.randint(0, N, (M,))
+    y = F.linear(x, w, b)
+    loss = F.cross_entropy(y, lab) * 0.7
+    loss.backward()
+    yd = K.linear_fwd(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev))
+    ld, dl = K.softmax_ce(yd, lab.to(dev), 0.7)
+    dx, dw, db = K.linear_bwd(x.detach().to(dev), w.detach().to(dev), dl)
+    p1 = K.softmax_prob1(yd)
+    torch.cuda.synchronize()
+    assert float((yd.cpu() - y.detach()).abs().max()) < 1e-4
+    assert abs(float(ld.cpu()) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert float((dx.cpu() - x.grad).abs().max()) < 1e-5
+    assert float((dw.cpu() - w.grad).abs().max()) < 1e-5
+    assert float((db.cpu() - b.grad).abs().max()) < 1e-5
+    assert float((p1.cpu() - F.softmax(y.detach(), 1)[:, 1]).abs().max()) < 1e-6
+    # relu-terminated linear (count regressor)
+    y2 = torch.relu(F.linear(x, w[:1], b[:1]))
+    t = torch.tensor([0., 3., 12., 40., 1., 25., 7., 0., 100.])
+    x.grad = None; w.grad = None; b.grad = None
+    l2 = ((y2.squeeze() - t) ** 2).mean()
+    l2.backward()
+    y2d = K.linear_fwd(x.detach().to(dev), w.detach()[:1].contiguous().to(dev), b.detach()[:1].contiguous().to(dev), K.CS_ACT_RELU)
+    l2d, dy2 = K.mse(y2d.view(-1), t.to(dev))
+    dx2, dw2, db2 = K.linear_bwd(x.detach().to(dev), w.detach()[:1].contiguous().to(dev), dy2.view(M, 1), y2d, K.CS_ACT_RELU)
+    torch.cuda.synchronize()
+    assert abs(float(l2d.cpu()) - float(l2)) < 1e-4 * max(1.0, abs(float(l2)))
+    assert float((dx2.cpu() - x.grad).abs().max()) < 1e-4 * max(1.0, float(x.grad.abs().max()))
+    assert float((dw2.cpu() - w.grad[:1]).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
+    # weighted mse known answer from the reference (metrics/metrics.py:23-33)
+    lw, _ = K.mse(torch.tensor([1., 25., 30.]).to(dev), torch.tensor([2., 20., 40.]).to(dev), weighted=True)
+    torch.cuda.synchronize()
+    assert abs(float(lw.cpu()) - 148.59375) < 1e-3
+
+
+def _sample_reference(probs, groups, labels, tiles_per_pos, topk_neg):
+    """inference.py:31-43 restated in numpy (the oracle for the selection kernel)."""
+    groups = np.asarray(groups)
+    order = np.lexsort((probs, groups))
+    T = len(groups)
+    index = np.empty(T, 'bool')
+    for i in range(T):
+        lab = labels[groups[i]]
+        topk = topk_neg if lab == 0 else lab * tiles_per_pos
+        index[i] = groups[i] != groups[(i + topk) % T]
+    return order[index]
+
+
+def _run_topk(probs, groups, labels, tiles_per_pos, topk_neg, dev):
+    groups = np.asarray(groups)
+    lab = np.asarray([labels[g] for g in groups])
+    kpt = np.where(lab == 0, topk_neg, lab * tiles_per_pos).astype(np.int32)
+    starts = np.flatnonzero(np.r_[True, groups[1:] != groups[:-1]])
+    offs = np.r_[starts, len(groups)].astype(np.int64)
+    out, cnt = K.segmented_topk(torch.from_numpy(probs).to(dev), torch.from_numpy(groups.astype(np.int32)).to(dev),
+                                torch.from_numpy(kpt).to(dev), torch.from_numpy(offs).to(dev), int(np.diff(offs).max()))
+    torch.cuda.synchronize()
+    n = int(cnt.cpu())
+    return out[:n].cpu().numpy()
+
+
+def test_topk_known_answer(dev):
+    # probed on the reference
+    groups = [1] * 5 + [2] * 5 + [3] * 5
+    labels = {1: 2, 2: 0, 3: 1}
+    probs = np.random.RandomState(0).rand(15).astype(np.float32)
+    got = _run_topk(probs, groups, labels, 1, 3, dev)
+    assert got.tolist() == [2, 1, 5, 7, 8, 13]
+    assert got.tolist() == _sample_reference(probs, groups, labels, 1, 3).tolist()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_topk_random_ragged_with_ties(seed, dev):
+    rs = np.random.RandomState(seed)
+    n_img = 37
+    sizes = rs.randint(1, 400, size=n_img)
+    sizes[3] = 1
+    sizes[5] = 3364          # 16x16 tiles stride 5 (train_seg.py:225-232)
+    groups = np.repeat(np.arange(n_img), sizes)
+    labels = {g: int(rs.choice([0, 0, 1, 2, 5, 40])) for g in range(n_img)}
+    probs = rs.rand(len(groups)).astype(np.float32)
+    probs[rs.rand(len(groups)) < 0.3] = 0.5            # heavy ties
+    probs[:7] = np.float32(-0.0)
+    probs[7:11] = np.float32(0.0)
+    for kp, kn in [(1, 30), (3, 5), (1, 0)]:
+        got = _run_topk(probs, groups, labels, kp, kn, dev)
+        ref = _sample_reference(probs, groups, labels, kp, kn)
+        assert got.tolist() == ref.tolist()
+
+
+def test_topk_single_group_wraps(dev):
+    # one bag of 64 tiles: (i+k) % T always lands in the same group -> nothing selected
+    probs = np.random.RandomState(4).rand(64).astype(np.float32)
+    got = _run_topk(probs, [0] * 64, {0: 0}, 1, 30, dev)
+    ref = _sample_reference(probs, [0] * 64, {0: 0}, 1, 30)
+    assert got.tolist() == ref.tolist() == []
