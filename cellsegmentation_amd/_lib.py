@@ -29,7 +29,7 @@ _SIGNATURES = {
     "cs_last_error": (c_char_p, []),
     "cs_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_nhwc_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "cs_bn_fold": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, _P]),
+    "cs_bn_fold": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, _P]),
     "cs_weight_prep": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "cs_conv2d_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "cs_conv2d_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, _P, _P]),
@@ -45,6 +45,19 @@ _SIGNATURES = {
     "cs_softmax_ce": (c_int, [_P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "cs_softmax_prob1": (c_int, [_P, _P, c_int, c_int, _P]),
     "cs_mse": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P]),
+    "cs_bn_stats": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
+    "cs_bn_finalize": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P, _P, c_int, _P]),
+    "cs_bn_apply": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_longlong, c_int, _P]),
+    "cs_bn_bwd_reduce": (c_int, [_P, _P, c_int, _P, _P, c_longlong, c_int, _P, _P]),
+    "cs_bn_bwd_apply": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_longlong, c_int, _P, _P, _P, _P]),
+    "cs_bilinear_ac_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cs_bilinear_ac_bwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cs_concat_channels": (c_int, [_P, _P, c_int, _P, c_longlong, c_int, c_int, _P]),
+    "cs_split_channels": (c_int, [_P, c_int, _P, _P, c_longlong, c_int, c_int, _P]),
+    "cs_dice_fwd": (c_int, [_P, _P, c_int, c_longlong, c_float, c_int, _P, _P, _P]),
+    "cs_dice_bwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_float, c_int, _P, _P]),
+    "cs_softmax_channel_fwd": (c_int, [_P, _P, c_int, c_int, c_longlong, c_int, _P]),
+    "cs_softmax_channel_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_longlong, c_int, _P]),
     "cs_segmented_topk_workspace": (c_size_t, [c_longlong]),
     "cs_segmented_topk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_longlong, _P, _P, _P, c_size_t, _P]),
 }

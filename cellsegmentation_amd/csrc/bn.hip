@@ -1,0 +1,277 @@
+// BatchNorm in TRAIN mode (batch statistics) for NHWC rows [M][C] -- used by the image-mode and
+// segment-mode trunks (model.train(): model/resnet.py:21,52,54,56,112,184,199) and by the
+// BatchNorm1d layers of the image heads (resnet.py:134,138,144,148; M = batch, C = features).
+//
+//   stats   : per-channel sum / sum of squares in fp64 (also produced by the conv epilogue)
+//   finalize: mean, rstd = 1/sqrt(biased var + eps); running stats updated with momentum and the
+//             UNBIASED variance, exactly like nn.BatchNorm2d
+//   apply   : y = act( gamma*(z-mean)*rstd + beta + residual )
+//   backward: reduce  s0 = sum g, s1 = sum g*xhat ;  dz = gamma*rstd*( g - s0/M - xhat*s1/M )
+// All HBM-bound: 8 channels (16 or 32 bytes) per thread, rows strided over the workgroup.
+#include "cs_common.h"
+
+namespace {
+
+// Two per-thread partial sums for 8 channels -> one fp64 atomic per channel per workgroup.
+// Threads are laid out tid = rr*width + (cg - cg0); rows rr < rpar hold valid partials.
+__device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const float (&b)[8], int width, int rpar, int cg, bool live,
+                                                  double* out0, double* out1) {
+    __shared__ float fold[2][256][8];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        fold[0][threadIdx.x][e] = live ? a[e] : 0.f;
+        fold[1][threadIdx.x][e] = live ? b[e] : 0.f;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < width) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int r = 0; r < rpar; ++r) {
+                t0 += (double)fold[0][r * width + threadIdx.x][e];
+                t1 += (double)fold[1][r * width + threadIdx.x][e];
+            }
+            atomicAdd(out0 + cg * 8 + e, t0);
+            atomicAdd(out1 + cg * 8 + e, t1);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, long long M, int C, double* __restrict__ stats,
+                                                       int rows_per_block) {
+    const int CG = C / 8;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+        const int rpar = 256 / width;
+        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int rr = threadIdx.x / width;
+        const bool live = rr < rpar;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        if (live) {
+            for (long long r = r0 + rr; r < r1; r += rpar) {
+                float v[8];
+                load8<T>(z + r * C + cg * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+            }
+        }
+        block_fold_atomic(s1, s2, width, rpar, cg, live, stats, stats + C);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long M, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c] / (double)M;
+    double var = stats[C + c] / (double)M - mean * mean;
+    if (var < 0) var = 0;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const T* __restrict__ residual,
+                                                       int act, T* __restrict__ y, long long M, int C) {
+    const int CG = C / 8;
+    const long long total = M * CG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        const long long off = (idx / CG) * C + cg * 8;
+        float v[8];
+        load8<T>(z + off, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            const float g = gamma ? gamma[c] : 1.f;
+            const float b = beta ? beta[c] : 0.f;
+            v[e] = (v[e] - mean[c]) * rstd[c] * g + b;
+        }
+        if (residual) {
+            float r8[8];
+            load8<T>(residual + off, r8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r8[e];
+        }
+        if (act == CS_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if (act == CS_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+        }
+        store8<T>(y + off, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            long long M, int C, double* __restrict__ sums,
+                                                            int rows_per_block) {
+    const int CG = C / 8;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+        const int rpar = 256 / width;
+        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int rr = threadIdx.x / width;
+        const bool live = rr < rpar;
+        float s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+        if (live) {
+            float mu[8], rs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = mean[cg * 8 + e]; rs[e] = rstd[cg * 8 + e]; }
+            for (long long r = r0 + rr; r < r1; r += rpar) {
+                float g[8], zz[8];
+                load8<T>(dy + r * C + cg * 8, g);
+                load8<T>(z + r * C + cg * 8, zz);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * (zz[e] - mu[e]) * rs[e]; }
+            }
+        }
+        block_fold_atomic(s0, s1, width, rpar, cg, live, sums, sums + C);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           long long M, int C, T* __restrict__ dz, float* dgamma, float* dbeta) {
+    const int CG = C / 8;
+    const long long total = M * CG;
+    const float invM = 1.f / (float)M;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dbeta) dbeta[c] = (float)sums[c];
+            if (dgamma) dgamma[c] = (float)sums[C + c];
+        }
+    }
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        const long long off = (idx / CG) * C + cg * 8;
+        float g[8], zz[8], o[8];
+        load8<T>(dy + off, g);
+        load8<T>(z + off, zz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            const float xh = (zz[e] - mean[c]) * rstd[c];
+            const float gm = gamma ? gamma[c] : 1.f;
+            o[e] = gm * rstd[c] * (g[e] - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
+        }
+        store8<T>(dz + off, o);
+    }
+}
+
+inline int rows_per_block_for(long long M) {
+    long long r = (M + 1023) / 1024;
+    if (r < 64) r = 64;
+    return (int)r;
+}
+
+inline int grid_ew(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define CS_DISPATCH_T(dtype, CALL_F32, CALL_BF16, NAME)      \
+    if (dtype == CS_F32) { CALL_F32; }                       \
+    else if (dtype == CS_BF16) { CALL_BF16; }                \
+    else { cs_set_error_(NAME ": bad dtype"); return CS_ERR_INVALID_ARG; }
+
+extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, void* stream) {
+    CS_CHECK_ARG(z && stats && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = rows_per_block_for(M);
+    const int blocks = (int)((M + rpb - 1) / rpb);
+    CS_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, M, C, stats, rpb),
+                  hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, M, C, stats, rpb),
+                  "bn_stats");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_bn_finalize(const double* stats, long long M, float eps, float momentum, float* running_mean,
+                              float* running_var, float* mean_out, float* rstd_out, int C, void* stream) {
+    CS_CHECK_ARG(stats && mean_out && rstd_out && M > 0 && C > 0, "bn_finalize: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, M, eps, momentum, running_mean,
+                       running_var, mean_out, rstd_out, C);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream) {
+    CS_CHECK_ARG(z && y && mean && rstd && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_ew(M * (C / 8));
+    CS_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, mean, rstd, gamma, beta,
+                                     (const float*)residual, act, (float*)y, M, C),
+                  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)z, mean, rstd, gamma, beta,
+                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C),
+                  "bn_apply");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd, long long M,
+                                int C, double* sums, void* stream) {
+    CS_CHECK_ARG(dy && z && mean && rstd && sums && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = rows_per_block_for(M);
+    const int blocks = (int)((M + rpb - 1) / rpb);
+    CS_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
+                                     rstd, M, C, sums, rpb),
+                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z,
+                                     mean, rstd, M, C, sums, rpb),
+                  "bn_bwd_reduce");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
+                               const float* gamma, const double* sums, long long M, int C, void* dz, float* dgamma,
+                               float* dbeta, void* stream) {
+    CS_CHECK_ARG(dy && z && mean && rstd && sums && dz && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_ew(M * (C / 8));
+    CS_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
+                                     rstd, gamma, sums, M, C, (float*)dz, dgamma, dbeta),
+                  hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, mean,
+                                     rstd, gamma, sums, M, C, (bf16_t*)dz, dgamma, dbeta),
+                  "bn_bwd_apply");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}

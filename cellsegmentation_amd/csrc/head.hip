@@ -120,6 +120,84 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, c
     if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
 }
 
+
+// ---- Dice (train/losses.py:44-62, metrics/metrics.py:36-53): per-sample a=sum p*t, b=sum p^2, c=sum t^2
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ p, const float* __restrict__ t, long long HW,
+                                                        double* __restrict__ sums) {
+    const int n = blockIdx.y;
+    const float* pp = p + (long long)n * HW;
+    const float* tt = t + (long long)n * HW;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+        const float x = pp[i], y = tt[i];
+        a += x * y; b += x * x; c += y * y;
+    }
+    __shared__ float red[3][4];
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double v = (double)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(sums + n * 3 + threadIdx.x, v);
+    }
+}
+
+__global__ void dice_loss_kernel(const double* __restrict__ sums, int N, float eps, int mean, float* __restrict__ loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float a = (float)sums[n * 3], b = (float)sums[n * 3 + 1], c = (float)sums[n * 3 + 2];
+        acc += 1.f - (2.f * a + eps) / (b + c + eps);
+    }
+    loss[0] = mean ? acc / (float)N : acc;
+}
+
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                       const double* __restrict__ sums, long long HW, float eps, float scale,
+                                                       float* __restrict__ dp) {
+    const int n = blockIdx.y;
+    const float a = (float)sums[n * 3], b = (float)sums[n * 3 + 1], c = (float)sums[n * 3 + 2];
+    const float num = 2.f * a + eps, den = b + c + eps;
+    const float k = -scale / (den * den);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+        const long long o = (long long)n * HW + i;
+        dp[o] = k * (2.f * t[o] * den - num * 2.f * p[o]);
+    }
+}
+
+// softmax over the channel axis of NCHW logits, channel `ch` only (F.softmax(out)[:, 1], train/train.py:189)
+__global__ __launch_bounds__(256) void softmax_ch_fwd_kernel(const float* __restrict__ logits, float* __restrict__ pc, int C, int ch,
+                                                             long long HW, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long n = idx / HW, i = idx - n * HW;
+        const float* r = logits + n * C * HW + i;
+        float mx = r[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c * HW]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(r[c * HW] - mx);
+        pc[idx] = expf(r[ch * HW] - mx) / se;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_ch_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dpc,
+                                                             float* __restrict__ dlogits, int C, int ch, long long HW,
+                                                             long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long n = idx / HW, i = idx - n * HW;
+        const float* r = logits + n * C * HW + i;
+        float mx = r[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c * HW]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(r[c * HW] - mx);
+        const float pch = expf(r[ch * HW] - mx) / se;
+        const float g = dpc[idx];
+        for (int c = 0; c < C; ++c) {
+            const float pcv = expf(r[c * HW] - mx) / se;
+            dlogits[n * C * HW + c * HW + i] = g * pch * ((c == ch ? 1.f : 0.f) - pcv);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act,
@@ -176,6 +254,52 @@ extern "C" int cs_mse(const float* x, const float* t, int weighted, int mean, fl
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { cs_set_error_("mse: memset failed"); return CS_ERR_LAUNCH; }
     const float inv = mean ? 1.f / (float)M : 1.f;
     hipLaunchKernelGGL(mse_kernel, dim3((M + 255) / 256), dim3(256), 0, st, x, t, weighted, inv, loss, dx, M);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_dice_fwd(const float* p, const float* t, int N, long long HW, float eps, int mean, double* sums, float* loss,
+                           void* stream) {
+    CS_CHECK_ARG(p && t && sums && loss && N > 0 && HW > 0, "dice_fwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * N, st) != hipSuccess) { cs_set_error_("dice_fwd: memset failed"); return CS_ERR_LAUNCH; }
+    long long bx = (HW + 256 * 8 - 1) / (256 * 8);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)bx, N), dim3(256), 0, st, p, t, HW, sums);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_loss_kernel, dim3(1), dim3(64), 0, st, sums, N, eps, mean, loss);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_dice_bwd(const float* p, const float* t, const double* sums, int N, long long HW, float eps, int mean, float* dp,
+                           void* stream) {
+    CS_CHECK_ARG(p && t && sums && dp && N > 0 && HW > 0, "dice_bwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long long bx = (HW + 256 * 4 - 1) / (256 * 4);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)bx, N), dim3(256), 0, st, p, t, sums, HW, eps, mean ? 1.f / (float)N : 1.f, dp);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_softmax_channel_fwd(const float* logits, float* pc, int N, int C, long long HW, int ch, void* stream) {
+    CS_CHECK_ARG(logits && pc && N > 0 && C > 1 && HW > 0 && ch >= 0 && ch < C, "softmax_channel_fwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)N * HW;
+    long long b = (total + 255) / 256; if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(softmax_ch_fwd_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, pc, C, ch, HW, total);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_softmax_channel_bwd(const float* logits, const float* dpc, float* dlogits, int N, int C, long long HW, int ch,
+                                      void* stream) {
+    CS_CHECK_ARG(logits && dpc && dlogits && N > 0 && C > 1 && HW > 0 && ch >= 0 && ch < C, "softmax_channel_bwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)N * HW;
+    long long b = (total + 255) / 256; if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(softmax_ch_bwd_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, dpc, dlogits, C, ch, HW, total);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -51,7 +51,7 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ y, float* __restrict__
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                               float* scale, float* shift, float* rstd, int C) {
+                               const float* conv_bias, float* scale, float* shift, float* rstd, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     // same operation order as ATen's eval batch_norm: invstd = 1/sqrt(var+eps)
@@ -60,7 +60,7 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     const float b = beta ? beta[c] : 0.f;
     const float s = g * r;
     if (scale) scale[c] = s;
-    if (shift) shift[c] = b - mean[c] * s;
+    if (shift) shift[c] = b + ((conv_bias ? conv_bias[c] : 0.f) - mean[c]) * s;
     if (rstd) rstd[c] = r;
 }
 
@@ -70,14 +70,14 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
                                    int S, int Cp, int Kp, T* __restrict__ w_khwc, T* __restrict__ w_chwk) {
     const int RS = R * S;
     if (w_khwc) {
-        const long long total = (long long)K * RS * Cp;
+        const long long total = (long long)Kp * RS * Cp;
         for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
              idx += (long long)gridDim.x * blockDim.x) {
             const int c = (int)(idx % Cp);
             const int rs = (int)((idx / Cp) % RS);
             const int k = (int)(idx / ((long long)Cp * RS));
             float v = 0.f;
-            if (c < Cin) {
+            if (c < Cin && k < K) {
                 v = w[((long long)k * Cin + c) * RS + rs];
                 if (scale) v *= scale[k];
             }
@@ -85,14 +85,14 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
         }
     }
     if (w_chwk) {
-        const long long total = (long long)Cin * RS * Kp;
+        const long long total = (long long)Cp * RS * Kp;
         for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
              idx += (long long)gridDim.x * blockDim.x) {
             const int k = (int)(idx % Kp);
             const int rs = (int)((idx / Kp) % RS);
             const int c = (int)(idx / ((long long)Kp * RS));
             float v = 0.f;
-            if (k < K) {
+            if (k < K && c < Cin) {
                 v = w[((long long)k * Cin + c) * RS + rs];
                 if (scale) v *= scale[k];
             }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
                 dgamma[k] = accumulate ? dgamma[k] + v : v;
             }
             if (dbeta) dbeta[k] = accumulate ? dbeta[k] + gs : gs;
-            if (dbias) dbias[k] = accumulate ? dbias[k] + gs : gs;
+            if (dbias) dbias[k] = accumulate ? dbias[k] + sc * gs : sc * gs;
         }
     }
 }
@@ -213,10 +213,10 @@ extern "C" int cs_nhwc_to_nchw(const void* y, int dtype, float* x, int N, int C,
 }
 
 extern "C" int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                          float* scale, float* shift, float* rstd, int C, void* stream) {
+                          const float* conv_bias, float* scale, float* shift, float* rstd, int C, void* stream) {
     CS_CHECK_ARG(mean && var && C > 0, "bn_fold: NULL statistics");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, scale, shift, rstd, C);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, conv_bias, scale, shift, rstd, C);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
@@ -226,7 +226,7 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
     CS_CHECK_ARG(w && (w_khwc || w_chwk), "weight_prep: NULL tensor");
     CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "weight_prep: bad extents");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long long t1 = (long long)K * R * S * Cp, t2 = (long long)Cin * R * S * Kp;
+    const long long t1 = (long long)Kp * R * S * Cp, t2 = (long long)Cp * R * S * Kp;
     const long long total = t1 > t2 ? t1 : t2;
     if (dtype == CS_F32)
         hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, scale, K, Cin, R, S, Cp, Kp,

@@ -1,0 +1,370 @@
+"""Plan executor: the explicit forward/backward kernel schedule of a CNN trunk on MI355X.
+
+A *plan* is a list of fused units over numbered tensor slots (NHWC, bf16 or fp32):
+
+* ``ConvUnit``     Conv2d (+bias) [+ BatchNorm2d] [+ residual add] [+ ReLU]
+                   - BN in eval mode (``freeze_bn`` / ``model.eval()``): BN is folded into the
+                     staged weights + a per-channel shift, everything fused in the conv epilogue;
+                     its backward derives dgamma/dbeta from the raw weight gradient (no conv
+                     output is kept).
+                   - BN in train mode: conv (+fused per-channel fp64 statistics) -> finalize ->
+                     normalise+residual+ReLU kernel; backward = 2-pass BN backward + dgrad/wgrad.
+* ``PoolUnit``     MaxPool2d(3,2,1)
+* ``UpsampleUnit`` bilinear, align_corners=True
+* ``ConcatUnit``   channel concat
+
+Gradient convention: a gradient w.r.t. a post-ReLU tensor is always stored already multiplied
+by [tensor > 0]; the kernel producing the LAST contribution to a slot applies the mask (dgrad and
+bilinear-backward epilogues), so ReLU backward never costs a separate pass, and residual
+gradients are passed as the ``add`` operand of the dgrad epilogue instead of a separate add.
+
+The whole plan is ONE torch.autograd.Function: torch only sees (inputs, parameters) -> outputs.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import kernels as K
+
+ACT_NONE, ACT_RELU = K.CS_ACT_NONE, K.CS_ACT_RELU
+
+
+class ConvUnit:
+    kind = "conv"
+
+    def __init__(self, name, conv, bn, act, src, dst, res=None):
+        self.name, self.conv, self.bn, self.act = name, conv, bn, act
+        self.src, self.dst, self.res = src, dst, res
+        if conv.groups != 1:
+            raise NotImplementedError(f"{name}: grouped convolution is not on the HIP path yet")
+        self._cache = None
+
+    def params(self):
+        out = [("weight", self.conv.weight)]
+        if self.conv.bias is not None:
+            out.append(("bias", self.conv.bias))
+        if self.bn is not None:
+            out += [("gamma", self.bn.weight), ("beta", self.bn.bias)]
+        return out
+
+    def inputs(self):
+        return [self.src] + ([self.res] if self.res is not None else [])
+
+
+class PoolUnit:
+    kind = "pool"
+
+    def __init__(self, src, dst):
+        self.src, self.dst = src, dst
+
+    def params(self):
+        return []
+
+    def inputs(self):
+        return [self.src]
+
+
+class UpsampleUnit:
+    kind = "up"
+
+    def __init__(self, src, dst, size_like=None, size_fn=None):
+        """output size = spatial size of slot ``size_like`` or ``size_fn(input_hw_of_plan)``"""
+        self.src, self.dst, self.size_like, self.size_fn = src, dst, size_like, size_fn
+
+    def params(self):
+        return []
+
+    def inputs(self):
+        return [self.src]
+
+
+class ConcatUnit:
+    kind = "cat"
+
+    def __init__(self, a, b, dst):
+        self.a, self.b, self.dst = a, b, dst
+
+    def params(self):
+        return []
+
+    def inputs(self):
+        return [self.a, self.b]
+
+
+class Plan:
+    def __init__(self, units, inputs, outputs, relu_inputs=()):
+        self.units, self.inputs, self.outputs = units, list(inputs), list(outputs)
+        self.relu_slots = set(relu_inputs)
+        for u in units:
+            if u.kind == "conv" and u.act == ACT_RELU:
+                self.relu_slots.add(u.dst)
+            elif u.kind == "pool" and u.src in self.relu_slots:
+                self.relu_slots.add(u.dst)       # max of non-negative values; see PoolUnit backward
+            elif u.kind == "cat" and u.a in self.relu_slots and u.b in self.relu_slots:
+                self.relu_slots.add(u.dst)
+        self.consumers = {}
+        for u in units:
+            for s in u.inputs():
+                self.consumers[s] = self.consumers.get(s, 0) + 1
+        self.param_list = []          # [(unit_index, role, tensor)]
+        for ui, u in enumerate(units):
+            for role, t in u.params():
+                self.param_list.append((ui, role, t))
+
+    def param_tensors(self):
+        return [t for _, _, t in self.param_list]
+
+
+def _pad_vec(v, n):
+    if v is None or v.numel() == n:
+        return v
+    out = torch.zeros((n,), dtype=v.dtype, device=v.device)
+    out[: v.numel()] = v
+    return out
+
+
+def _bn_uses_batch_stats(bn, bn_train):
+    return bn is not None and bn_train and bn.training
+
+
+def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded):
+    """BN folding + weight staging, cached while the parameters are unchanged (frozen encoders)."""
+    conv, bn = u.conv, u.bn
+    key_t = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+    key = (dtype, Cp, Kp, need_bwd, folded) + tuple((t._version, t.data_ptr()) if t is not None else None for t in key_t)
+    if u._cache is not None and u._cache[0] == key:
+        return u._cache[1]
+    w = conv.weight.detach()
+    bias = conv.bias.detach() if conv.bias is not None else None
+    scale = shift = rstd = None
+    if folded and bn is not None:
+        scale, shift, rstd = K.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bias)
+    else:
+        shift = bias
+    w_khwc, w_chwk = K.weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=need_bwd)
+    staged = SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=_pad_vec(shift, Kp), rstd=rstd)
+    u._cache = (key, staged)
+    return staged
+
+
+def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
+    """feeds: {slot: NHWC tensor}.  Returns state with .t (slot tensors) and .aux (per unit)."""
+    t = dict(feeds)
+    aux = [None] * len(plan.units)
+    remaining = dict(plan.consumers)
+    in_hw = image_hw
+    if in_hw is None:
+        in_hw = tuple(t[plan.inputs[0]].shape[1:3])
+
+    def release(s):
+        if save or s in plan.outputs:
+            return
+        remaining[s] -= 1
+        if remaining[s] == 0:
+            t.pop(s, None)
+
+    for ui, u in enumerate(plan.units):
+        if u.kind == "conv":
+            x = t[u.src]
+            N, H, W, Cp = x.shape
+            conv = u.conv
+            Kc = conv.out_channels
+            Kp = K.pad_channels(Kc)
+            R, S = conv.kernel_size
+            geom = K.make_geom(N, H, W, Cp, Kp, R, S, conv.stride[0], conv.padding[0])
+            res = t[u.res] if u.res is not None else None
+            need_bwd = save and requires.get(u.src, False)
+            batch_stats = _bn_uses_batch_stats(u.bn, bn_train)
+            st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats)
+            if not batch_stats:
+                y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act)
+                aux[ui] = SimpleNamespace(geom=geom, st=st, train=False)
+            else:
+                bn = u.bn
+                stats = K.new_stats(Kp, x.device)
+                z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats)
+                M = N * geom.P * geom.Q
+                momentum = bn.momentum if bn.momentum is not None else 0.1
+                mean, rstd = K.bn_finalize(stats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
+                                           bn.running_var if bn.track_running_stats else None)
+                if bn.track_running_stats and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+                y = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), res, u.act)
+                aux[ui] = SimpleNamespace(geom=geom, st=st, train=True, z=z if save else None, mean=mean, rstd=rstd)
+            t[u.dst] = y
+        elif u.kind == "pool":
+            y, am = K.maxpool_fwd(t[u.src], want_argmax=save)
+            aux[ui] = SimpleNamespace(argmax=am, in_hw=tuple(t[u.src].shape[1:3]))
+            t[u.dst] = y
+        elif u.kind == "up":
+            x = t[u.src]
+            size = tuple(t[u.size_like].shape[1:3]) if u.size_like is not None else tuple(u.size_fn(in_hw))
+            t[u.dst] = K.bilinear_fwd(x, size)
+            aux[ui] = SimpleNamespace(in_hw=tuple(x.shape[1:3]))
+        elif u.kind == "cat":
+            a, b = t[u.a], t[u.b]
+            t[u.dst] = K.concat(a, b)
+            aux[ui] = SimpleNamespace(ca=a.shape[-1])
+        for s in u.inputs():
+            release(s)
+    return SimpleNamespace(t=t, aux=aux, in_hw=in_hw)
+
+
+def compute_requires(plan, param_needs, input_needs):
+    """requires[slot]: does anything upstream of (and including the producer of) slot need a gradient?"""
+    requires = {s: bool(input_needs.get(s, False)) for s in plan.inputs}
+    pi = 0
+    unit_trainable = []
+    for u in plan.units:
+        n = len(u.params())
+        unit_trainable.append(any(param_needs[pi:pi + n]))
+        pi += n
+    for ui, u in enumerate(plan.units):
+        requires[u.dst] = unit_trainable[ui] or any(requires.get(s, False) for s in u.inputs())
+    return requires, unit_trainable
+
+
+def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
+    """grad_feeds: {output slot: grad (already ReLU-masked where the slot is post-ReLU)}.
+    Returns ({input slot: grad}, [param grads in plan.param_list order])."""
+    t, aux = state.t, state.aux
+    grads = dict(grad_feeds)
+    gsum_cache = {}
+    left = dict(plan.consumers)
+    pgrads = [None] * len(plan.param_list)
+    pindex = {}
+    for i, (ui, role, _) in enumerate(plan.param_list):
+        pindex[(ui, role)] = i
+
+    def need(ui, role):
+        i = pindex.get((ui, role))
+        return i is not None and param_needs[i]
+
+    def contribute(slot, g, masked):
+        """Non-fused contribution (alias when first)."""
+        left[slot] -= 1
+        if slot in grads:
+            raise NotImplementedError("engine: unfused gradient accumulation is not expected for these networks")
+        if left[slot] == 0 and slot in plan.relu_slots and not masked:
+            raise NotImplementedError("engine: last contribution to a post-ReLU slot must come from a masking kernel")
+        grads[slot] = g
+
+    for ui in reversed(range(len(plan.units))):
+        u = plan.units[ui]
+        g = grads.pop(u.dst, None)
+        a = aux[ui]
+        if g is None:
+            continue
+        if u.kind == "conv":
+            conv = u.conv
+            Kc, Cin = conv.out_channels, conv.in_channels
+            geom = a.geom
+            x = t[u.src]
+            if u.res is not None and requires.get(u.res, False):
+                contribute(u.res, g, masked=False)
+            want_w = need(ui, "weight")
+            want_b = need(ui, "bias")
+            want_bn = need(ui, "gamma") or need(ui, "beta")
+            dz = g
+            if a.train:
+                bn = u.bn
+                dz, dgamma, dbeta = K.bn_bwd(g, a.z, a.mean, a.rstd, bn.weight.detach(), want_param_grads=want_bn)
+                if need(ui, "gamma"):
+                    pgrads[pindex[(ui, "gamma")]] = dgamma[:Kc]
+                if need(ui, "beta"):
+                    pgrads[pindex[(ui, "beta")]] = dbeta[:Kc]
+            if want_w or want_b or (want_bn and not a.train):
+                gsum = None
+                if want_b or (want_bn and not a.train):
+                    gsum = gsum_cache.pop(u.dst, None) if not a.train else None
+                    if gsum is None:
+                        gsum = K.colsum(dz)
+                raw = torch.zeros((geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
+                K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read)
+                dw = torch.empty_like(conv.weight)
+                dbias = torch.empty_like(conv.bias) if want_b else None
+                dgamma = dbeta = None
+                if want_bn and not a.train:
+                    dgb = torch.empty((2, Kc), dtype=torch.float32, device=x.device)
+                    dgamma, dbeta = dgb[0], dgb[1]
+                K.wgrad_finalize(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
+                                 None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, Cin, dw,
+                                 dbias=dbias, dgamma=dgamma, dbeta=dbeta)
+                if want_w:
+                    pgrads[pindex[(ui, "weight")]] = dw
+                if want_b:
+                    pgrads[pindex[(ui, "bias")]] = dbias
+                if dgamma is not None:
+                    if need(ui, "gamma"):
+                        pgrads[pindex[(ui, "gamma")]] = dgamma
+                    if need(ui, "beta"):
+                        pgrads[pindex[(ui, "beta")]] = dbeta
+            gsum_cache.pop(u.dst, None)
+            if requires.get(u.src, False):
+                left[u.src] -= 1
+                final = left[u.src] == 0
+                pending = grads.pop(u.src, None)
+                mask = x if (u.src in plan.relu_slots and final) else None
+                cs = torch.zeros((geom.C,), dtype=torch.float32, device=x.device) if final else None
+                dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs)
+                grads[u.src] = dx
+                if final:
+                    gsum_cache[u.src] = cs
+        elif u.kind == "pool":
+            if requires.get(u.src, False):
+                left[u.src] -= 1
+                if u.src in grads:
+                    raise NotImplementedError("engine: pool input with several consumers")
+                # dy is masked by [pool_out>0]; the argmax element equals pool_out, so dx is masked too
+                grads[u.src] = K.maxpool_bwd(g, a.argmax, None, a.in_hw)
+        elif u.kind == "up":
+            if requires.get(u.src, False):
+                left[u.src] -= 1
+                if u.src in grads:
+                    raise NotImplementedError("engine: upsample input with several consumers")
+                mask = t[u.src] if u.src in plan.relu_slots else None
+                grads[u.src] = K.bilinear_bwd(g, a.in_hw, mask=mask)
+        elif u.kind == "cat":
+            na, nb = requires.get(u.a, False), requires.get(u.b, False)
+            if na or nb:
+                ga, gb = K.split(g, a.ca, want_a=na, want_b=nb)
+                if na:
+                    contribute(u.a, ga, masked=True)
+                if nb:
+                    contribute(u.b, gb, masked=True)
+    return {s: grads.get(s) for s in plan.inputs}, pgrads
+
+
+class _PlanFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, cfg, n_inputs, *tensors):
+        inputs, params = tensors[:n_inputs], tensors[n_inputs:]
+        feeds = {s: x for s, x in zip(plan.inputs, inputs)}
+        input_needs = {s: ctx.needs_input_grad[3 + i] for i, s in enumerate(plan.inputs)}
+        param_needs = [ctx.needs_input_grad[3 + n_inputs + i] for i in range(len(params))]
+        save = any(param_needs) or any(input_needs.values())
+        requires, _ = compute_requires(plan, param_needs, input_needs)
+        state = forward(plan, feeds, cfg.dtype, cfg.bn_train, save, requires, cfg.image_hw)
+        ctx.plan, ctx.cfg, ctx.n_inputs = plan, cfg, n_inputs
+        ctx.param_needs, ctx.requires = param_needs, requires
+        ctx.state = state if save else None
+        outs = tuple(state.t[s] for s in plan.outputs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        plan = ctx.plan
+        grad_feeds = {}
+        for s, g in zip(plan.outputs, gouts):
+            if g is not None:
+                grad_feeds[s] = g.contiguous()
+        in_grads, pgrads = backward(plan, ctx.state, grad_feeds, ctx.param_needs, ctx.requires, ctx.cfg.use_tr_read)
+        ctx.state = None
+        return (None, None, None) + tuple(in_grads[s] for s in plan.inputs) + tuple(pgrads)
+
+
+def run_plan(plan, inputs, dtype, bn_train, use_tr_read=True, image_hw=None):
+    """Differentiable execution of a plan. inputs: NHWC tensors for plan.inputs; returns NHWC outputs.
+    image_hw: spatial size of the network input (for UpsampleUnit.size_fn)."""
+    cfg = SimpleNamespace(dtype=dtype, bn_train=bn_train, use_tr_read=use_tr_read, image_hw=image_hw)
+    return _PlanFunction.apply(plan, cfg, len(inputs), *inputs, *plan.param_tensors())

@@ -70,18 +70,18 @@ def to_nchw(y, C):
 
 
 # ---------------------------------------------------------------- parameters
-def bn_fold(gamma, beta, mean, var, eps):
+def bn_fold(gamma, beta, mean, var, eps, conv_bias=None):
     C = mean.numel()
     out = torch.empty((3, C), dtype=torch.float32, device=mean.device)
-    _lib.check(_lib.load().cs_bn_fold(_p(gamma), _p(beta), _p(mean), _p(var), eps, _p(out[0]), _p(out[1]), _p(out[2]), C,
-                                      _stream()), "bn_fold")
+    _lib.check(_lib.load().cs_bn_fold(_p(gamma), _p(beta), _p(mean), _p(var), eps, _p(conv_bias), _p(out[0]), _p(out[1]), _p(out[2]),
+                                      C, _stream()), "bn_fold")
     return out[0], out[1], out[2]
 
 
 def weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=False):
     K, Cin, R, S = w.shape
-    w_khwc = torch.empty((K, R, S, Cp), dtype=dtype, device=w.device) if want_fwd else None
-    w_chwk = torch.empty((Cin, R, S, Kp), dtype=dtype, device=w.device) if want_bwd else None
+    w_khwc = torch.empty((Kp, R, S, Cp), dtype=dtype, device=w.device) if want_fwd else None
+    w_chwk = torch.empty((Cp, R, S, Kp), dtype=dtype, device=w.device) if want_bwd else None
     _lib.check(_lib.load().cs_weight_prep(_p(w), _p(scale), _code(dtype), K, Cin, R, S, Cp, Kp, _p(w_khwc), _p(w_chwk),
                                           _stream()), "weight_prep")
     return w_khwc, w_chwk
@@ -110,7 +110,8 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True):
 
 
 def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False):
-    K, R, S, Cp = dw_raw.shape
+    _, R, S, Cp = dw_raw.shape
+    K = dw.shape[0]
     _lib.check(_lib.load().cs_wgrad_finalize(_p(dw_raw), _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K, Cin, R, S, Cp,
                                              _p(dw), _p(dbias), _p(dgamma), _p(dbeta), 1 if accumulate else 0, _stream()),
                "wgrad_finalize")
@@ -123,6 +124,87 @@ def colsum(g, out=None):
         out = torch.zeros((C,), dtype=torch.float32, device=g.device)
     _lib.check(_lib.load().cs_colsum(_p(g), _code(g.dtype), M, C, _p(out), _stream()), "colsum")
     return out
+
+
+# ---------------------------------------------------------------- BatchNorm (train mode)
+def new_stats(C, device):
+    return torch.zeros((2, C), dtype=torch.float64, device=device)
+
+
+def bn_stats(z, stats=None):
+    C = z.shape[-1]
+    M = z.numel() // C
+    if stats is None:
+        stats = new_stats(C, z.device)
+    _lib.check(_lib.load().cs_bn_stats(_p(z), _code(z.dtype), M, C, _p(stats), _stream()), "bn_stats")
+    return stats
+
+
+def bn_finalize(stats, M, eps, momentum, running_mean=None, running_var=None):
+    C = stats.shape[1]
+    out = torch.empty((2, C), dtype=torch.float32, device=stats.device)
+    _lib.check(_lib.load().cs_bn_finalize(_p(stats), M, eps, momentum, _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]), C,
+                                          _stream()), "bn_finalize")
+    return out[0], out[1]
+
+
+def bn_apply(z, mean, rstd, gamma, beta, residual=None, act=CS_ACT_NONE, out=None):
+    C = z.shape[-1]
+    M = z.numel() // C
+    y = out if out is not None else torch.empty_like(z)
+    _lib.check(_lib.load().cs_bn_apply(_p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), act, _p(y), M, C,
+                                       _stream()), "bn_apply")
+    return y
+
+
+def bn_bwd(dy, z, mean, rstd, gamma, want_param_grads=True):
+    """returns dz, dgamma, dbeta"""
+    C = z.shape[-1]
+    M = z.numel() // C
+    sums = new_stats(C, z.device)
+    lib = _lib.load()
+    _lib.check(lib.cs_bn_bwd_reduce(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), M, C, _p(sums), _stream()), "bn_bwd_reduce")
+    dz = torch.empty_like(z)
+    dg = torch.empty((2, C), dtype=torch.float32, device=z.device) if want_param_grads else None
+    _lib.check(lib.cs_bn_bwd_apply(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(sums), M, C, _p(dz),
+                                   _p(dg[0]) if dg is not None else None, _p(dg[1]) if dg is not None else None, _stream()),
+               "bn_bwd_apply")
+    return dz, (dg[0] if dg is not None else None), (dg[1] if dg is not None else None)
+
+
+# ---------------------------------------------------------------- decoder data movement
+def bilinear_fwd(x, out_hw):
+    N, H, W, C = x.shape
+    P, Q = out_hw
+    y = torch.empty((N, P, Q, C), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().cs_bilinear_ac_fwd(_p(x), _code(x.dtype), _p(y), N, H, W, C, P, Q, _stream()), "bilinear_fwd")
+    return y
+
+
+def bilinear_bwd(dy, in_hw, mask=None):
+    N, P, Q, C = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().cs_bilinear_ac_bwd(_p(dy), _p(mask), _code(dy.dtype), _p(dx), N, H, W, C, P, Q, _stream()), "bilinear_bwd")
+    return dx
+
+
+def concat(a, b):
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    M = a.numel() // Ca
+    out = torch.empty(tuple(a.shape[:-1]) + (Ca + Cb,), dtype=a.dtype, device=a.device)
+    _lib.check(_lib.load().cs_concat_channels(_p(a), _p(b), _code(a.dtype), _p(out), M, Ca, Cb, _stream()), "concat")
+    return out
+
+
+def split(whole, Ca, want_a=True, want_b=True):
+    C = whole.shape[-1]
+    Cb = C - Ca
+    M = whole.numel() // C
+    a = torch.empty(tuple(whole.shape[:-1]) + (Ca,), dtype=whole.dtype, device=whole.device) if want_a else None
+    b = torch.empty(tuple(whole.shape[:-1]) + (Cb,), dtype=whole.dtype, device=whole.device) if want_b else None
+    _lib.check(_lib.load().cs_split_channels(_p(whole), _code(whole.dtype), _p(a), _p(b), M, Ca, Cb, _stream()), "split")
+    return a, b
 
 
 # ---------------------------------------------------------------- pooling
@@ -201,6 +283,37 @@ def mse(x, t, weighted=False, mean=True, want_grad=True):
     dx = torch.empty_like(x) if want_grad else None
     _lib.check(_lib.load().cs_mse(_p(x), _p(t), 1 if weighted else 0, 1 if mean else 0, _p(loss), _p(dx), M, _stream()), "mse")
     return loss, dx
+
+
+def dice_fwd(p, t, eps=1e-6, mean=True):
+    """p, t: [N, HW] fp32 contiguous. returns loss[1], sums[N,3] fp64"""
+    N, HW = p.shape
+    sums = torch.empty((N, 3), dtype=torch.float64, device=p.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.load().cs_dice_fwd(_p(p), _p(t), N, HW, eps, 1 if mean else 0, _p(sums), _p(loss), _stream()), "dice_fwd")
+    return loss, sums
+
+
+def dice_bwd(p, t, sums, eps=1e-6, mean=True):
+    N, HW = p.shape
+    dp = torch.empty_like(p)
+    _lib.check(_lib.load().cs_dice_bwd(_p(p), _p(t), _p(sums), N, HW, eps, 1 if mean else 0, _p(dp), _stream()), "dice_bwd")
+    return dp
+
+
+def softmax_channel_fwd(logits, ch=1):
+    """logits [N,C,H,W] fp32 -> softmax over C, channel ch: [N,H,W]"""
+    N, C, H, W = logits.shape
+    pc = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().cs_softmax_channel_fwd(_p(logits), _p(pc), N, C, H * W, ch, _stream()), "softmax_channel_fwd")
+    return pc
+
+
+def softmax_channel_bwd(logits, dpc, ch=1):
+    N, C, H, W = logits.shape
+    dl = torch.empty_like(logits)
+    _lib.check(_lib.load().cs_softmax_channel_bwd(_p(logits), _p(dpc), _p(dl), N, C, H * W, ch, _stream()), "softmax_channel_bwd")
+    return dl
 
 
 def segmented_topk(probs, groups, k_per_tile, seg_offsets, max_run):

@@ -53,15 +53,35 @@ int cs_nhwc_to_nchw(const void* y, int dtype, float* x, int N, int C, int H, int
 
 /* ---- BatchNorm2d in eval mode folded to per-channel scale/shift (resnet.py:254-258: the
  * freeze_bn path runs every BN with running statistics) --------------------------------------
- * scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, rstd = rsqrt(var+eps). */
+ * scale = gamma*rsqrt(var+eps), shift = beta + (conv_bias - mean)*scale, rstd = rsqrt(var+eps);
+ * conv_bias nullable (the biased 3x3 convs of upsample_conv, resnet.py:198). */
 int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-               float* scale, float* shift, float* rstd, int C, void* stream);
+               const float* conv_bias, float* scale, float* shift, float* rstd, int C, void* stream);
+
+/* ---- BatchNorm in train mode (batch statistics; model.train(), resnet.py:21,52,112,184,199 and the
+ * BatchNorm1d of the image heads, resnet.py:134,138) over NHWC rows z[M][C] ----------------------
+ * stats: fp64 [2][C] (sum, sum of squares), zeroed by the caller; also filled by cs_conv2d_fwd. */
+int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, void* stream);
+/* mean, rstd = 1/sqrt(biased var+eps); running_* (nullable) updated in place with `momentum` and the
+ * unbiased variance, as nn.BatchNorm2d does. */
+int cs_bn_finalize(const double* stats, long long M, float eps, float momentum, float* running_mean,
+                   float* running_var, float* mean_out, float* rstd_out, int C, void* stream);
+/* y = act( gamma*(z-mean)*rstd + beta + residual ); gamma/beta/residual nullable. */
+int cs_bn_apply(const void* z, int dtype, const float* mean, const float* rstd, const float* gamma,
+                const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream);
+/* sums fp64 [2][C] (zeroed by caller): sum dy, sum dy*xhat with xhat=(z-mean)*rstd. */
+int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd, long long M,
+                     int C, double* sums, void* stream);
+/* dz = gamma*rstd*( dy - sums0/M - xhat*sums1/M ); dgamma=sums1, dbeta=sums0 (fp32, nullable). */
+int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
+                    const float* gamma, const double* sums, long long M, int C, void* dz, float* dgamma,
+                    float* dbeta, void* stream);
 
 /* ---- weight staging -------------------------------------------------------------------------
  * w[K][Cin][R][S] fp32 (torch Conv2d.weight) times optional per-K `scale` ->
- *   w_khwc [K ][R][S][Cp]  (forward operand, Cp = padded Cin)      if non-NULL
- *   w_chwk [Cin_rows][R][S][Kp] (dgrad operand, Kp = padded K)      if non-NULL
- * Cin_rows = number of rows written in w_chwk (== Cin, must already be a chunk multiple). */
+ *   w_khwc [Kp][R][S][Cp]  (forward operand)   if non-NULL
+ *   w_chwk [Cp][R][S][Kp]  (dgrad operand)     if non-NULL
+ * Cp/Kp = stored (padded) channel counts; padded rows/columns are zero-filled. */
 int cs_weight_prep(const float* w, const float* scale, int dtype, int K, int Cin, int R, int S, int Cp, int Kp,
                    void* w_khwc, void* w_chwk, void* stream);
 
@@ -83,7 +103,7 @@ int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* 
 int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                     int use_tr_read, void* stream);
 /* dw[K][Cin][R][S] (torch layout, ACCUMULATED into when accumulate!=0) = scale[k]*dw_khwc[k][r][s][c];
- * and, when dgamma/dbeta non-NULL, the eval-mode BatchNorm parameter gradients
+ * dbias[k] = scale[k]*gsum[k] (conv bias); and, when dgamma/dbeta non-NULL, the eval-mode BatchNorm parameter gradients
  *   dbeta[k] = gsum[k];  dgamma[k] = rstd[k]*( sum_j w[k][j]*dw_raw[k][j] - mean[k]*gsum[k] ). */
 int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, const float* rstd,
                       const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp,
@@ -109,6 +129,16 @@ int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, in
 int cs_gap_avgmax_bwd(const float* dfeat, const int32_t* argmax, const void* x, int dtype, void* dx, int N, int HW,
                       int C, int relu_mask, void* stream);
 
+/* ---- segmentation decoder data movement ------------------------------------------------------
+ * F.interpolate(mode="bilinear", align_corners=True) (resnet.py:282,287,292,297,300): x[N][H][W][C] -> y[N][P][Q][C] */
+int cs_bilinear_ac_fwd(const void* x, int dtype, void* y, int N, int H, int W, int C, int P, int Q, void* stream);
+/* dx = interpolate^T(dy) * [mask>0] (mask nullable, shaped like dx: the ReLU output that was upsampled) */
+int cs_bilinear_ac_bwd(const void* dy, const void* mask, int dtype, void* dx, int N, int H, int W, int C, int P, int Q,
+                       void* stream);
+/* torch.cat([a,b], dim=1) in NHWC (resnet.py:284,289,294): out[M][Ca+Cb]; and its inverse (a or b nullable). */
+int cs_concat_channels(const void* a, const void* b, int dtype, void* out, long long M, int Ca, int Cb, void* stream);
+int cs_split_channels(const void* whole, int dtype, void* a, void* b, long long M, int Ca, int Cb, void* stream);
+
 /* ---- heads: Linear (resnet.py:126,137,140,150), losses (train/train.py:34,80-83) ------------- */
 /* y[M][N] = x[M][K] @ w[N][K]^T + b[N]  (fp32; b nullable; act applied last) */
 int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act, void* stream);
@@ -124,6 +154,17 @@ int cs_softmax_prob1(const float* logits, float* p1, int M, int C, void* stream)
 /* sum or mean of w_i*(x_i-t_i)^2, w_i = 1 (weighted==0) or the reference's weighted_mse weights
  * (metrics/metrics.py:23-33: ln(t) if t>=20 else t).  dx nullable. scale = upstream grad factor. */
 int cs_mse(const float* x, const float* t, int weighted, int mean, float* loss, float* dx, int M, void* stream);
+
+/* Dice loss (train/losses.py:44-62 over metrics/metrics.py:36-53) on p[N][HW], t[N][HW] fp32:
+ * sums fp64 [N][3] = (sum p*t, sum p^2, sum t^2); loss = mean|sum over n of 1-(2a+eps)/(b+c+eps). */
+int cs_dice_fwd(const float* p, const float* t, int N, long long HW, float eps, int mean, double* sums, float* loss,
+                void* stream);
+int cs_dice_bwd(const float* p, const float* t, const double* sums, int N, long long HW, float eps, int mean, float* dp,
+                void* stream);
+/* F.softmax(logits, dim=1)[:, ch] on NCHW fp32 logits[N][C][HW] (train/train.py:189) and its backward. */
+int cs_softmax_channel_fwd(const float* logits, float* pc, int N, int C, long long HW, int ch, void* stream);
+int cs_softmax_channel_bwd(const float* logits, const float* dpc, float* dlogits, int N, int C, long long HW, int ch,
+                           void* stream);
 
 /* ---- adaptive top-k instance selection (inference.py:31-43) ---------------------------------
  * probs[T] fp32, groups[T] int32 non-decreasing, k_per_tile[T] int32 (k of the tile's group).

@@ -1,0 +1,207 @@
+"""End-to-end GPU parity of the HIP models against the REFERENCE's own outputs (committed golden
+vectors, tests/golden/reference_vectors.npz, produced by tests/golden/make_golden.py from
+/root/reference) in fp32 parity mode: logits / loss / gradients within 1e-4 relative
+(BASELINE.json north_star tolerance), plus a bf16 sanity band.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import synth  # noqa: E402
+from cellsegmentation_amd import functional as HF  # noqa: E402
+from cellsegmentation_amd.model import resnet as R  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"), allow_pickle=False)
+FACT = {"resnet18": R.MILresnet18, "resnet34": R.MILresnet34, "resnet50": R.MILresnet50}
+RTOL = 1e-4
+
+
+def build(arch, dev, dtype=torch.float32):
+    torch.manual_seed(0)
+    m = FACT[arch]()
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m.to(dev).set_compute_dtype(dtype)
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def digest(t):
+    t = t.detach().double().flatten().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()] + t[:5].tolist() + t[-1:].tolist())
+
+
+def check_grads(tag, params, errs, rtol, keys=None):
+    for key in GOLD.files:
+        pre = f"{tag}/gradfull/"
+        if not key.startswith(pre):
+            continue
+        name = key[len(pre):]
+        g = params[name].grad
+        if g is None:
+            errs.append(f"{name}: no grad")
+            continue
+        got = g.detach().flatten()[:4096].cpu().numpy()
+        want = GOLD[key].flatten()
+        scale = np.sqrt(GOLD[f"{tag}/grad/{name}"][2] / max(1, params[name].numel()))   # rms of the full reference grad
+        e = float(np.abs(got - want).max() / (max(np.abs(want).max(), scale) + 1e-30))
+        if e > rtol:
+            errs.append(f"grad {name}: rel err {e:.2e}")
+        d_got, d_want = digest(g), GOLD[f"{tag}/grad/{name}"]
+        if abs(d_got[1] - d_want[1]) > rtol * 5 * abs(d_want[1]) + 1e-12:
+            errs.append(f"grad {name}: abs-sum {d_got[1]:.6e} vs {d_want[1]:.6e}")
+
+
+@pytest.mark.parametrize("arch,size", [("resnet18", 32), ("resnet18", 299), ("resnet34", 64), ("resnet50", 32), ("resnet50", 299)])
+def test_tile_mode_matches_reference_fp32(arch, size, dev):
+    tag = f"{arch}/tile{size}"
+    n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])
+    x = synth.normalise(synth.ihc_tiles(n, size, seed))
+    assert np.allclose(digest(x)[:3], GOLD[f"{tag}/x_digest"][:3], rtol=1e-6)
+    labels = torch.from_numpy(GOLD[f"{tag}/labels"]).to(dev)
+    m = build(arch, dev)
+    errs = []
+    # inference_tiles semantics (inference.py:9-28)
+    m.setmode("tile")
+    m.eval()
+    with torch.no_grad():
+        logits = m(x.to(dev))
+        probs = torch.softmax(logits, 1)[:, 1]
+    e = rel(logits.cpu(), GOLD[f"{tag}/logits_eval"])
+    if e > RTOL:
+        errs.append(f"eval logits rel err {e:.2e}")
+    e = rel(probs.cpu(), GOLD[f"{tag}/probs"])
+    if e > RTOL:
+        errs.append(f"probs rel err {e:.2e}")
+    # --scratch training step (train/train.py:32-36 with encoder grads on)
+    m.train()
+    m.set_encoder_grads(True)
+    m.zero_grad()
+    out = m(x.to(dev), freeze_bn=True)
+    assert m.training, "reference leaves the module in train mode after the freeze_bn flip"
+    loss = HF.cross_entropy(out, labels, 1.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    e = rel(out.detach().cpu(), GOLD[f"{tag}/logits_train"])
+    if e > RTOL:
+        errs.append(f"train logits rel err {e:.2e}")
+    if abs(loss.item() - float(GOLD[f"{tag}/loss"])) > RTOL * abs(float(GOLD[f"{tag}/loss"])):
+        errs.append(f"loss {loss.item():.7f} vs {float(GOLD[tag + '/loss']):.7f}")
+    check_grads(tag, dict(m.named_parameters()), errs, 2e-4)
+    assert not errs, "\n".join(errs)
+
+
+def test_tile_mode_default_frozen_encoder(dev):
+    """Reference default stage 2: encoder frozen, only fc_tile gets gradients (resnet.py:315-319)."""
+    tag = "resnet50/tile32"
+    n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])
+    x = synth.normalise(synth.ihc_tiles(n, 32, seed)).to(dev)
+    labels = torch.from_numpy(GOLD[f"{tag}/labels"]).to(dev)
+    m = build("resnet50", dev)
+    m.setmode("tile")
+    m.train()
+    loss = HF.cross_entropy(m(x, freeze_bn=True), labels)
+    loss.backward()
+    params = dict(m.named_parameters())
+    assert params["conv1.weight"].grad is None and params["layer4.2.conv3.weight"].grad is None
+    for k in ("fc_tile.1.weight", "fc_tile.1.bias"):
+        assert rel(params[k].grad.flatten()[:4096].cpu(), GOLD[f"{tag}/gradfull/{k}"].flatten()) < 2e-4
+
+
+@pytest.mark.parametrize("arch,size", [("resnet18", 299), ("resnet50", 96)])
+def test_image_mode_matches_reference_fp32(arch, size, dev):
+    tag = f"{arch}/image{size}"
+    n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])
+    x = synth.normalise(synth.ihc_tiles(n, size, seed)).to(dev)
+    counts = torch.from_numpy(GOLD[f"{tag}/counts"]).to(dev)
+    cls = torch.from_numpy(GOLD[f"{tag}/cls"]).to(dev)
+    m = build(arch, dev)
+    m.setmode("image")
+    m.train()
+    m.zero_grad()
+    out_cls, out_reg = m(x)
+    l_cls = HF.cross_entropy(out_cls, cls)
+    l_reg = HF.mse_loss(out_reg.squeeze(), counts.float())
+    loss = 1.0 * l_cls + 1.0 * l_reg
+    loss.backward()
+    torch.cuda.synchronize()
+    errs = []
+    for name, got in (("out_cls", out_cls), ("out_reg", out_reg)):
+        e = rel(got.detach().cpu(), GOLD[f"{tag}/{name}"])
+        if e > 2e-4:
+            errs.append(f"{name} rel err {e:.2e}")
+    for name, got in (("loss_cls", l_cls), ("loss_reg", l_reg), ("loss", loss)):
+        want = float(GOLD[f"{tag}/{name}"])
+        if abs(got.item() - want) > 2e-4 * abs(want):
+            errs.append(f"{name} {got.item():.7f} vs {want:.7f}")
+    bufs = dict(m.named_buffers())
+    for k in ("bn1.running_mean", "bn1.running_var"):
+        e = rel(bufs[k].cpu(), GOLD[f"{tag}/{k}"])
+        if e > 1e-5:
+            errs.append(f"{k} rel err {e:.2e}")
+    assert int(bufs["bn1.num_batches_tracked"]) == 1
+    check_grads(tag, dict(m.named_parameters()), errs, 1e-3)
+    # eval-mode inference (inference.py:46-101)
+    m.eval()
+    with torch.no_grad():
+        e_cls, e_reg = m(x)
+    for name, got in (("eval_out_cls", e_cls), ("eval_out_reg", e_reg)):
+        e = rel(got.cpu(), GOLD[f"{tag}/{name}"])
+        if e > 2e-4:
+            errs.append(f"{name} rel err {e:.2e}")
+    assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_segment_mode_matches_reference_fp32(arch, dev):
+    tag = f"{arch}/seg299"
+    n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])
+    x = synth.normalise(synth.ihc_tiles(n, 299, seed)).to(dev)
+    mask = np.unpackbits(GOLD[f"{tag}/mask_packed"])[: n * 299 * 299].reshape(n, 299, 299).astype(np.float32)
+    m01 = torch.from_numpy(mask).to(dev)
+    m = build(arch, dev)
+    m.setmode("segment")
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad) == GOLD[f"{tag}/trainable"].tolist()
+    m.train()
+    m.zero_grad()
+    out = m(x)
+    assert tuple(out.shape) == (n, 2, 299, 299)
+    dice = HF.dice_loss(HF.softmax_channel(out, 1), m01)
+    dice.backward()
+    torch.cuda.synchronize()
+    errs = []
+    e = rel(out.detach()[:, :, ::37, ::41].cpu(), GOLD[f"{tag}/logits_sample"])
+    if e > 2e-4:
+        errs.append(f"logits sample rel err {e:.2e}")
+    want = float(GOLD[f"{tag}/dice"])
+    if abs(dice.item() - want) > 2e-4 * abs(want):
+        errs.append(f"dice {dice.item():.7f} vs {want:.7f}")
+    params = dict(m.named_parameters())
+    assert params["conv1.weight"].grad is None
+    check_grads(tag, {k: v for k, v in params.items()}, errs, 2e-3)
+    assert not errs, "\n".join(errs)
+
+
+def test_bf16_throughput_mode_is_close(dev):
+    tag = "resnet50/tile299"
+    n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])
+    x = synth.normalise(synth.ihc_tiles(n, 299, seed)).to(dev)
+    m = build("resnet50", dev, torch.bfloat16)
+    m.setmode("tile")
+    m.eval()
+    with torch.no_grad():
+        logits = m(x)
+    want = GOLD[f"{tag}/logits_eval"]
+    assert rel(logits.float().cpu(), want) < 5e-2
