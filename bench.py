@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tiles/sec of one training step (fwd + CE loss + bwd [+ RCCL grad all-reduce] +
+Adam) of the ResNet-50 MIL tile classifier on a bag of 64 synthetic 299x299 IHC tiles per GPU, bf16
+(BASELINE.json configs[1]; `--scratch` semantics = encoder gradients on, BN frozen via freeze_bn,
+i.e. the reference loop body train/train.py:32-37).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     : the dominant conv kernel instantiation, timed per launch with HIP events on the launch stream
+  cpu_baseline : the CPU oracle (numerically the reference path) timed on this box's host cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cellsegmentation_amd import functional as HF  # noqa: E402
+from cellsegmentation_amd import kernels as K  # noqa: E402
+from cellsegmentation_amd import synth  # noqa: E402
+from cellsegmentation_amd.model import resnet as R  # noqa: E402
+from cellsegmentation_amd.parallel import GradReducer  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+BAG = 64
+SIZE = 299
+ARCH = "resnet50"
+
+
+def build_model(dev, dtype):
+    m = R.MILresnet50()
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    m = m.to(dev).set_compute_dtype(dtype)
+    m.setmode("tile")
+    m.set_encoder_grads(True)          # --scratch (train_tile.py:272-273): full conv backward
+    m.train()
+    return m
+
+
+def conv_flops(g):
+    c_true = 3 if (g["R"] == 7 and g["C"] == 8) else g["C"]
+    return 2.0 * g["N"] * g["P"] * g["Q"] * g["K"] * c_true * g["R"] * g["S"]
+
+
+def kernel_name(kind, g, dtype):
+    dt = "bf16" if dtype == torch.bfloat16 else "f32"
+    if kind == "wgrad":
+        return f"wgrad_kernel<{dt},{128 if g['K'] > 64 else 64},128>"
+    if kind == "fwd":
+        M, nout = g["N"] * g["P"] * g["Q"], g["K"]
+    else:
+        M, nout = g["N"] * g["H"] * g["W"], g["C"]
+    bm, bn = K.igemm_tile(M, nout)
+    return f"igemm_kernel<{dt},{bm},{bn}>"
+
+
+def roofline_from(records, steps, dtype):
+    per_kernel, per_family = {}, {}
+    for kind, g, dt, ms in records:
+        name = kernel_name(kind, g, dt)
+        fam = f"{g['R']}x{g['S']}/{kind}"
+        fl = conv_flops(g)
+        for table, key in ((per_kernel, name), (per_family, fam)):
+            e = table.setdefault(key, [0.0, 0.0, 0])
+            e[0] += fl; e[1] += ms; e[2] += 1
+    if not per_kernel:
+        return None
+    dom = max(per_kernel, key=lambda k: per_kernel[k][1])
+    fl, ms, n = per_kernel[dom]
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    achieved = fl / (ms * 1e-3) / 1e12
+    fams = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1] / steps, 3), "launches_per_step": v[2] // steps}
+            for k, v in sorted(per_family.items())}
+    kerns = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "avg_ms": round(v[1] / v[2], 4), "launches": v[2]}
+             for k, v in sorted(per_kernel.items())}
+    three = [v for k, v in per_family.items() if k.startswith("3x3")]
+    t3 = sum(v[0] for v in three) / (sum(v[1] for v in three) * 1e-3) / 1e12 if three else None
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": None, "kernel": dom, "avg_launch_ms": round(ms / n, 4), "launches": n,
+            "conv3x3_family_tflops": round(t3, 2) if t3 else None, "conv3x3_family_frac": round(t3 / peak, 4) if t3 else None,
+            "by_kernel": kerns, "by_family": fams}
+
+
+def cpu_baseline(sample_tiles=8, steps=2):
+    """The oracle (torch CPU fp32 NCHW, proven equal to the reference in tests/golden/make_golden.py)
+    on the same step definition, bounded sample."""
+    from oracle import cellseg_oracle as orc
+    cores = torch.get_num_threads()
+    x = synth.normalise(synth.ihc_tiles(sample_tiles, SIZE, 1234))
+    labels = torch.tensor([(i * 7 + 1) % 2 for i in range(sample_tiles)])
+    sd = orc.empty_state_dict(ARCH)
+    synth.fill_state_dict(sd)
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith(("fc_image", "upconv", "seg_out")):
+            v.requires_grad_()
+            params.append(v)
+    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = orc.tile_step_loss(sd, x, labels, ARCH)
+        loss.backward()
+        opt.step()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": round(sample_tiles / t, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_tiles} tiles x {steps} timed steps (1 warm-up), ResNet-50 tile fwd+bwd+Adam fp32, median",
+            "s_per_step": round(t, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    model = build_model(dev, dtype)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4)
+    reducer = GradReducer(params) if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_parameters(model)
+
+    # synthetic IHC tiles: a few distinct ones per rank, tiled to the bag (inputs resident in HBM)
+    base = synth.normalise(synth.ihc_tiles(8, SIZE, 1234 + rank))
+    x = base.repeat(BAG // 8, 1, 1, 1).contiguous().to(dev)
+    labels = torch.tensor([(i * 7 + 1) % 2 for i in range(BAG)], device=dev)
+    loss_acc = torch.zeros((), device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x, freeze_bn=True)
+        loss = HF.cross_entropy(out, labels, 1.0)
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+        opt.step()
+        loss_acc.add_(loss.detach())
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    timer = None if args.no_launch_timing else K.LaunchTimer()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if timer is not None:
+        with timer:
+            for _ in range(args.steps):
+                step()
+    else:
+        for _ in range(args.steps):
+            step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        final_loss = float(loss_acc.item()) / max(1, args.steps + args.warmup)
+        roof = roofline_from(timer.results(), args.steps, dtype) if timer is not None else None
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        out = {
+            "metric": "tiles/sec fwd+bwd (ResNet-50 MIL, 299x299)",
+            "value": round(world * BAG * args.steps / elapsed, 2),
+            "unit": "tiles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "ResNet-50 tile classifier (train_tile.py --scratch semantics: fwd + CE + full bwd + Adam), "
+                                   "bag=64 tiles of 299x299x3 per GPU, freeze_bn=True", "tiles_per_gpu": BAG,
+                       "parallelism": f"dp{world}", "mean_loss": round(final_loss, 5)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

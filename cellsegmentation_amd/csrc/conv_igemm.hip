@@ -305,18 +305,25 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     return CS_OK;
 }
 
+// Tile choice: wide-N tiles when there are enough output channels; shrink BM when the grid
+// would not fill the 256 CUs.  Returns BM*1000+BN.
+int igemm_tile(long long M, int NOUT) {
+    const long long mt128 = (M + 127) / 128;
+    if (NOUT > 64) {
+        const long long blocks = mt128 * ((NOUT + 127) / 128);
+        return blocks >= 384 ? 128128 : 64128;
+    }
+    return mt128 >= 384 ? 128064 : 64064;
+}
+
 template <typename T>
 int dispatch_igemm(const IgemmParams& p, hipStream_t st) {
-    // Tile choice: wide-N tiles when there are enough output channels; shrink BM when the grid
-    // would not fill the 256 CUs.
-    const long long mt128 = (p.M + 127) / 128;
-    if (p.NOUT > 64) {
-        const long long blocks = mt128 * ((p.NOUT + 127) / 128);
-        if (blocks >= 384) return launch_igemm<T, 128, 128>(p, st);
-        return launch_igemm<T, 64, 128>(p, st);
+    switch (igemm_tile(p.M, p.NOUT)) {
+        case 128128: return launch_igemm<T, 128, 128>(p, st);
+        case 64128: return launch_igemm<T, 64, 128>(p, st);
+        case 128064: return launch_igemm<T, 128, 64>(p, st);
+        default: return launch_igemm<T, 64, 64>(p, st);
     }
-    if (mt128 >= 384) return launch_igemm<T, 128, 64>(p, st);
-    return launch_igemm<T, 64, 64>(p, st);
 }
 
 int check_geom(const CsConvGeom* g, int dtype) {
@@ -333,6 +340,8 @@ int check_geom(const CsConvGeom* g, int dtype) {
 }
 
 }  // namespace
+
+extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_out); }
 
 extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
                              const float* shift, const void* residual, int act, void* y, double* stats, void* stream) {

@@ -88,24 +88,69 @@ def weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=False):
 
 
 # ---------------------------------------------------------------- convolution family
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of the conv family (used by bench.py for the roofline
+    object).  Events are recorded on torch's current stream = the stream the kernels run on."""
+
+    def __init__(self):
+        self.records = []      # (kind, geom tuple, dtype, start, end)
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+
+    def results(self):
+        """[(kind, geom dict, dtype, milliseconds)] -- call after torch.cuda.synchronize()."""
+        return [(k, g, d, s.elapsed_time(e)) for k, g, d, s, e in self.records]
+
+
+_timer = None
+
+
+def _timed(kind, geom, dtype, fn):
+    if _timer is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn()
+    e.record()
+    _timer.records.append((kind, {f: getattr(geom, f) for f, _ in geom._fields_}, dtype, s, e))
+    return rc
+
+
+def igemm_tile(M, n_out):
+    """(BM, BN) the fwd/dgrad dispatcher picks."""
+    v = _lib.load().cs_igemm_tile(int(M), int(n_out))
+    return v // 1000, v % 1000
+
+
 def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None):
     y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().cs_conv2d_fwd(ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift),
-                                         _p(residual), act, _p(y), _p(stats), _stream()), "conv2d_fwd")
+    lib = _lib.load()
+    _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd(
+        ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(stats), _stream())),
+        "conv2d_fwd")
     return y
 
 
 def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None):
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
-    _lib.check(_lib.load().cs_conv2d_dgrad(ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask),
-                                           _p(dx), _p(colsum), _stream()), "conv2d_dgrad")
+    lib = _lib.load()
+    _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
+        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _stream())), "conv2d_dgrad")
     return dx
 
 
 def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True):
     """dw_raw[K,R,S,Cp] fp32 (pre-zeroed) += wgrad."""
-    _lib.check(_lib.load().cs_conv2d_wgrad(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw_raw),
-                                           1 if use_tr_read else 0, _stream()), "conv2d_wgrad")
+    lib = _lib.load()
+    _lib.check(_timed("wgrad", geom, x.dtype, lambda: lib.cs_conv2d_wgrad(
+        ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw_raw), 1 if use_tr_read else 0, _stream())), "conv2d_wgrad")
     return dw_raw
 
 

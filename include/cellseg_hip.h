@@ -93,6 +93,9 @@ int cs_weight_prep(const float* w, const float* scale, int dtype, int K, int Cin
  *   (BatchNorm2d train-mode batch statistics). */
 int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
                   const float* shift, const void* residual, int act, void* y, double* stats, void* stream);
+/* Which BM x BN output tile the fwd/dgrad dispatcher uses for M output pixels x n_out channels
+ * (returns BM*1000+BN); lets bench.py / profiles name the kernel instantiation that ran. */
+int cs_igemm_tile(long long M, int n_out);
 /* data gradient: dx = ( conv_transpose(dy, w) + add ) * [mask > 0]; add/mask nullable, both shaped like x.
  *   `mask` is the conv's own input activation when that input came out of a ReLU (the ReLU backward of
  *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */

@@ -1,0 +1,30 @@
+"""Documentation tool (build container only): how far the fp32 reference path is from fp64 truth on
+the same inputs -- loss ~1e-7, gradients up to 1.5e-3 relative (argmax / ReLU-mask flips).  This bounds
+the gradient tolerance used in tests/test_model_parity_gpu.py (5e-3 = ~3x the reference own noise)."""
+import sys, numpy as np, torch
+sys.path.insert(0,'/root/repo')
+from cellsegmentation_amd import synth
+from oracle import cellseg_oracle as orc
+torch.set_num_threads(8)
+G = np.load('/root/repo/tests/golden/reference_vectors.npz')
+def run(arch, size, dtype, tag):
+    n, seed = int(G[f'{tag}/n']), int(G[f'{tag}/seed'])
+    x = synth.normalise(synth.ihc_tiles(n, size, seed)).to(dtype)
+    sd = orc.empty_state_dict(arch); synth.fill_state_dict(sd)
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k] = sd[k].to(dtype)
+            if 'running' not in k: sd[k].requires_grad_()
+    labels = torch.from_numpy(G[f'{tag}/labels'])
+    loss = orc.tile_step_loss(sd, x, labels, arch); loss.backward()
+    return loss.item(), {k: v.grad for k,v in sd.items() if v.requires_grad}
+for arch,size in [('resnet50',299),('resnet18',299)]:
+    tag=f'{arch}/tile{size}'
+    l32,g32 = run(arch,size,torch.float32,tag); l64,g64 = run(arch,size,torch.float64,tag)
+    print(arch, 'loss', l32, l64, abs(l32-l64)/abs(l64))
+    worst=[]
+    for k in g64:
+        if g64[k] is None or g32[k] is None: continue
+        e = ((g32[k].double()-g64[k]).abs().max()/ (g64[k].abs().max()+1e-30)).item()
+        worst.append((e,k))
+    worst.sort(reverse=True); print(worst[:8])
