@@ -96,7 +96,12 @@ def cpu_baseline(sample_tiles=8, steps=2):
     """The oracle (torch CPU fp32 NCHW, proven equal to the reference in tests/golden/make_golden.py)
     on the same step definition, bounded sample."""
     from oracle import cellseg_oracle as orc
-    cores = torch.get_num_threads()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("CELLSEG_CPU_THREADS", "16"))))   # a 1-GPU box share is 16 cores
+    torch.set_num_threads(cores)
     x = synth.normalise(synth.ihc_tiles(sample_tiles, SIZE, 1234))
     labels = torch.tensor([(i * 7 + 1) % 2 for i in range(sample_tiles)])
     sd = orc.empty_state_dict(ARCH)

@@ -31,8 +31,8 @@ struct IgemmParams {
     const float* shift;
     const void* residual;
     const void* mask;
-    float* colsum;    // fp32 [NOUT]  (dgrad: sums of stored output)
-    double* stats;    // fp64 [2][NOUT] (fwd: sum, sum of squares of stored output)
+    float* slab;      // nullable fp32 [gridDim.x][2][NOUT]: per-workgroup column sums / sums of squares of the
+                      // stored output (no atomics; cs_slab_reduce folds the rows afterwards)
     int SH, SW, SC;   // source extents, stored channels
     int DH, DW;       // destination spatial extents
     int NOUT;         // destination channels
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                 for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
             }
             store8<T>(dst + off, v);
-            if (p.colsum || p.stats) {
+            if (p.slab) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     // statistics are those of the STORED (rounded) values
@@ -271,27 +271,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             }
         }
     }
-    if (p.colsum || p.stats) {
-        // lanes with equal (lane % CG) own the same channels: fold them, then one atomic per wave.
+    if (p.slab) {
+        // fold the 256/CG threads that own the same 8 channels through LDS (Cs is dead now)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);        // [256][16]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < CG && ook) {
+            float t1[8], t2[8];
 #pragma unroll
-            for (int offl = 32; offl >= CG; offl >>= 1) {
-                s1[e] += __shfl_xor(s1[e], offl, 64);
-                s2[e] += __shfl_xor(s2[e], offl, 64);
+            for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+            for (int r = tid; r < 256; r += CG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t1[e] += red[r * 16 + e]; t2[e] += red[r * 16 + 8 + e]; }
             }
-        }
-        if (lane < CG && ook) {
+            float* row = p.slab + (long long)blockIdx.x * 2 * p.NOUT;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (p.colsum) atomicAdd(p.colsum + o + e, s1[e]);
-                if (p.stats) {
-                    atomicAdd(p.stats + o + e, (double)s1[e]);
-                    atomicAdd(p.stats + p.NOUT + o + e, (double)s2[e]);
-                }
-            }
+            for (int e = 0; e < 8; ++e) { row[o + e] = t1[e]; row[p.NOUT + o + e] = t2[e]; }
         }
     }
+}
+
+// out[c] += sum_rows slab[row][which][c]; one thread per channel, fp64 accumulation
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int rows, int nout, float* colsum,
+                                                          double* stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nout) return;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        a += (double)slab[(long long)r * 2 * nout + c];
+        if (stats) b += (double)slab[(long long)r * 2 * nout + nout + c];
+    }
+    if (colsum) colsum[c] += (float)a;
+    if (stats) { stats[c] += a; stats[nout + c] += b; }
 }
 
 template <typename T, int BM, int BN>
@@ -317,13 +330,21 @@ int igemm_tile(long long M, int NOUT) {
 }
 
 template <typename T>
-int dispatch_igemm(const IgemmParams& p, hipStream_t st) {
-    switch (igemm_tile(p.M, p.NOUT)) {
-        case 128128: return launch_igemm<T, 128, 128>(p, st);
-        case 64128: return launch_igemm<T, 64, 128>(p, st);
-        case 128064: return launch_igemm<T, 128, 64>(p, st);
-        default: return launch_igemm<T, 64, 64>(p, st);
+int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream_t st) {
+    int rc;
+    const int tile = igemm_tile(p.M, p.NOUT);
+    switch (tile) {
+        case 128128: rc = launch_igemm<T, 128, 128>(p, st); break;
+        case 64128: rc = launch_igemm<T, 64, 128>(p, st); break;
+        case 128064: rc = launch_igemm<T, 128, 64>(p, st); break;
+        default: rc = launch_igemm<T, 64, 64>(p, st); break;
     }
+    if (rc != CS_OK || !p.slab) return rc;
+    const int bm = tile / 1000;
+    const int rows = (int)((p.M + bm - 1) / bm);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((p.NOUT + 255) / 256), dim3(256), 0, st, p.slab, rows, p.NOUT, colsum, stats);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
 }
 
 int check_geom(const CsConvGeom* g, int dtype) {
@@ -343,16 +364,23 @@ int check_geom(const CsConvGeom* g, int dtype) {
 
 extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_out); }
 
+extern "C" size_t cs_conv2d_stats_workspace(long long M, int n_out) {
+    const int bm = igemm_tile(M, n_out) / 1000;
+    return (size_t)((M + bm - 1) / bm) * 2 * (size_t)n_out * sizeof(float);
+}
+
 extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
-                             const float* shift, const void* residual, int act, void* y, double* stats, void* stream) {
+                             const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
+                             void* stream) {
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
     CS_CHECK_ARG(x && w_khwc && y, "conv2d_fwd: NULL tensor");
+    CS_CHECK_ARG(!stats || workspace, "conv2d_fwd: stats need a workspace of cs_conv2d_stats_workspace() bytes");
     IgemmParams p{};
     const int ce = dtype == CS_F32 ? 4 : 8;
     p.src = x; p.wgt = w_khwc; p.dst = y;
     p.scale = scale; p.shift = shift; p.residual = residual; p.mask = nullptr;
-    p.colsum = nullptr; p.stats = stats;
+    p.slab = stats ? reinterpret_cast<float*>(workspace) : nullptr;
     p.SH = g->H; p.SW = g->W; p.SC = g->C;
     p.DH = g->P; p.DW = g->Q; p.NOUT = g->K;
     p.R = g->R; p.S = g->S;
@@ -362,21 +390,22 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     p.SCc = g->C / ce;
     p.Qtot = g->R * g->S * p.SCc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == CS_F32 ? dispatch_igemm<float>(p, st) : dispatch_igemm<bf16_t>(p, st);
+    return dtype == CS_F32 ? dispatch_igemm<float>(p, nullptr, stats, st) : dispatch_igemm<bf16_t>(p, nullptr, stats, st);
 }
 
 extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
-                               const void* mask, void* dx, float* colsum, void* stream) {
+                               const void* mask, void* dx, float* colsum, void* workspace, void* stream) {
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
     CS_CHECK_ARG(dy && w_chwk && dx, "conv2d_dgrad: NULL tensor");
+    CS_CHECK_ARG(!colsum || workspace, "conv2d_dgrad: colsum needs a workspace of cs_conv2d_stats_workspace() bytes");
     const int ce = dtype == CS_F32 ? 4 : 8;
     CS_CHECK_ARG(g->K % ce == 0, "conv2d_dgrad: stored K must be a chunk multiple");
     CS_CHECK_ARG(g->C % 8 == 0, "conv2d_dgrad: stored C must be a multiple of 8");
     IgemmParams p{};
     p.src = dy; p.wgt = w_chwk; p.dst = dx;
     p.scale = nullptr; p.shift = nullptr; p.residual = add; p.mask = mask;
-    p.colsum = colsum; p.stats = nullptr;
+    p.slab = colsum ? reinterpret_cast<float*>(workspace) : nullptr;
     p.SH = g->P; p.SW = g->Q; p.SC = g->K;
     p.DH = g->H; p.DW = g->W; p.NOUT = g->C;
     p.R = g->R; p.S = g->S;
@@ -386,7 +415,7 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     p.SCc = g->K / ce;
     p.Qtot = g->R * g->S * p.SCc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == CS_F32 ? dispatch_igemm<float>(p, st) : dispatch_igemm<bf16_t>(p, st);
+    return dtype == CS_F32 ? dispatch_igemm<float>(p, colsum, nullptr, st) : dispatch_igemm<bf16_t>(p, colsum, nullptr, st);
 }
 
 // =============================================================================================

@@ -123,6 +123,11 @@ def _timed(kind, geom, dtype, fn):
     return rc
 
 
+def _stats_ws(M, n_out, device):
+    nbytes = _lib.load().cs_conv2d_stats_workspace(int(M), int(n_out))
+    return torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
+
+
 def igemm_tile(M, n_out):
     """(BM, BN) the fwd/dgrad dispatcher picks."""
     v = _lib.load().cs_igemm_tile(int(M), int(n_out))
@@ -132,17 +137,20 @@ def igemm_tile(M, n_out):
 def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None):
     y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
     lib = _lib.load()
+    ws = _stats_ws(geom.N * geom.P * geom.Q, geom.K, x.device) if stats is not None else None
     _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd(
-        ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(stats), _stream())),
-        "conv2d_fwd")
+        ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(stats), _p(ws),
+        _stream())), "conv2d_fwd")
     return y
 
 
 def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None):
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
+    ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if colsum is not None else None
     _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
-        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _stream())), "conv2d_dgrad")
+        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _p(ws), _stream())),
+        "conv2d_dgrad")
     return dx
 
 

@@ -89,10 +89,14 @@ int cs_weight_prep(const float* w, const float* scale, int dtype, int K, int Cin
  * forward: y = act( scale[k]*conv(x,w) + shift[k] + residual ), any of scale/shift/residual NULL.
  *   Fuses Conv2d+BatchNorm2d(eval)+ReLU(+residual add) of BasicBlock/Bottleneck.forward
  *   (resnet.py:28-43, 60-78) and Conv2d(bias) of upsample_conv/seg_out_conv (resnet.py:195-200,164).
- *   stats (nullable, fp64 [2][K]): accumulates sum and sum of squares of the STORED output per channel
+ *   stats (nullable, fp64 [2][K], needs `workspace`): accumulates sum and sum of squares of the STORED output per channel
  *   (BatchNorm2d train-mode batch statistics). */
 int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
-                  const float* shift, const void* residual, int act, void* y, double* stats, void* stream);
+                  const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
+                  void* stream);
+/* bytes of `workspace` that cs_conv2d_fwd (stats) / cs_conv2d_dgrad (colsum) need for M destination
+ * pixels x n_out destination channels: per-workgroup partial sums, folded without atomics. */
+size_t cs_conv2d_stats_workspace(long long M, int n_out);
 /* Which BM x BN output tile the fwd/dgrad dispatcher uses for M output pixels x n_out channels
  * (returns BM*1000+BN); lets bench.py / profiles name the kernel instantiation that ran. */
 int cs_igemm_tile(long long M, int n_out);
@@ -100,7 +104,7 @@ int cs_igemm_tile(long long M, int n_out);
  *   `mask` is the conv's own input activation when that input came out of a ReLU (the ReLU backward of
  *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */
 int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
-                    const void* mask, void* dx, float* colsum, void* stream);
+                    const void* mask, void* dx, float* colsum, void* workspace, void* stream);
 /* weight gradient, raw: dw_khwc[K][R][S][Cp] fp32 += sum over pixels dy (x) im2col(x).
  *   The caller zeroes dw_khwc first; split-K partial sums are combined with fp32 atomics. */
 int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
