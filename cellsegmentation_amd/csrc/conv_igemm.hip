@@ -293,18 +293,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
 }
 
-// out[c] += sum_rows slab[row][which][c]; one thread per channel, fp64 accumulation
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int rows, int nout, float* colsum,
-                                                          double* stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nout) return;
-    double a = 0.0, b = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        a += (double)slab[(long long)r * 2 * nout + c];
-        if (stats) b += (double)slab[(long long)r * 2 * nout + nout + c];
+// Fold the per-workgroup partial rows: out[c] += sum_r slab[r][c] for c < ncols (row stride = stride).
+// Workgroup = 64 columns x 4 row lanes, gridDim.y row chunks -> <= gridDim.y atomics per address.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int rows, int stride, int ncols,
+                                                          int nout, float* colsum, double* stats) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per;
+    int r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    double acc = 0.0;
+    if (c < ncols)
+        for (int r = r0 + rl; r < r1; r += 4) acc += (double)slab[(long long)r * stride + c];
+    __shared__ double red[4][64];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < ncols) {
+        const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (colsum && c < nout) atomicAdd(colsum + c, (float)t);
+        if (stats) atomicAdd(stats + c, t);
     }
-    if (colsum) colsum[c] += (float)a;
-    if (stats) { stats[c] += a; stats[nout + c] += b; }
 }
 
 template <typename T, int BM, int BN>
@@ -342,7 +351,12 @@ int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream
     if (rc != CS_OK || !p.slab) return rc;
     const int bm = tile / 1000;
     const int rows = (int)((p.M + bm - 1) / bm);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((p.NOUT + 255) / 256), dim3(256), 0, st, p.slab, rows, p.NOUT, colsum, stats);
+    const int ncols = stats ? 2 * p.NOUT : p.NOUT;
+    int chunks = rows / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 32) chunks = 32;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((ncols + 63) / 64, chunks), dim3(256), 0, st, p.slab, rows, 2 * p.NOUT, ncols, p.NOUT,
+                       colsum, stats);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

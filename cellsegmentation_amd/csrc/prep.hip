@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
     }
 }
 
-// ---- column sums: out[c] += sum_m g[m][c].  Thread owns 8 channels, block owns a row slab. -----
+// ---- column sums: out[c] += sum_m g[m][c].  Thread owns 8 channels over a strided row set, the
+// workgroup folds its threads through LDS and issues ONE atomic per channel. ---------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, long long M, int C, float* __restrict__ out,
                                                      int rows_per_block) {
@@ -147,12 +148,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    // thread t handles channel group (t % CG') over rows stepping by (256 / CG') when CG <= 256
+    __shared__ float fold[256][8];
     for (int cg0 = 0; cg0 < CG; cg0 += 256) {
-        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;   // groups handled this pass
-        // largest power-of-two row parallelism
-        int rpar = 256 / width;
-        if (rpar < 1) rpar = 1;
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+        const int rpar = 256 / width;
         const int cg = cg0 + (int)(threadIdx.x % width);
         const int rr = threadIdx.x / width;
         float acc[8];
@@ -165,8 +164,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += v[e];
             }
+        }
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(out + cg * 8 + e, acc[e]);
+        for (int e = 0; e < 8; ++e) fold[threadIdx.x][e] = acc[e];
+        __syncthreads();
+        if ((int)threadIdx.x < width) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = 0.f;
+                for (int r = 0; r < rpar; ++r) t += fold[r * width + threadIdx.x][e];
+                atomicAdd(out + cg * 8 + e, t);
+            }
         }
     }
 }
@@ -258,8 +267,8 @@ extern "C" int cs_colsum(const void* g, int dtype, long long M, int C, float* ou
     CS_CHECK_ARG(g && out, "colsum: NULL tensor");
     CS_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "colsum: C must be a positive multiple of 8");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // ~2048 blocks, at least 64 rows each
-    long long rows = (M + 2047) / 2048;
+    // ~512 workgroups (2 per CU), at least 64 rows each: <= 512 atomics per channel
+    long long rows = (M + 511) / 512;
     if (rows < 64) rows = 64;
     const int blocks = (int)((M + rows - 1) / rows);
     if (dtype == CS_F32)

@@ -279,6 +279,8 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                     gsum = gsum_cache.pop(u.dst, None) if not a.train else None
                     if gsum is None:
                         gsum = K.colsum(dz)
+                    if not a.train and u.res is not None and grads.get(u.res) is g:
+                        gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
                 raw = torch.zeros((geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
                 K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read)
                 dw = torch.empty_like(conv.weight)
