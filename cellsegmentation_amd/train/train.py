@@ -1,0 +1,133 @@
+"""Epoch loops with the reference's signatures (train/train.py:12-207).
+
+The loop bodies are the timed "step" of the hot path: zero_grad -> HIP forward -> HIP loss ->
+HIP backward -> optimizer.step.  Two deliberate host-side differences from the reference, neither
+changing results: the per-step ``loss.item()`` sync is replaced by an on-device accumulator read once
+per epoch, and ``print`` of ce/dice per step in train_seg is dropped (the CE there is never used).
+"""
+import torch
+from torch.optim.lr_scheduler import CyclicLR, OneCycleLR
+
+from .. import functional as HF
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    def tqdm(x, **kw):
+        return x
+
+
+def _per_step(scheduler):
+    return isinstance(scheduler, (CyclicLR, OneCycleLR))
+
+
+def _ce(criterion, output, label, gamma=1.0):
+    """nn.CrossEntropyLoss instances are routed to the HIP softmax-CE kernel; anything else is called as is."""
+    if isinstance(criterion, torch.nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean" \
+            and getattr(criterion, "label_smoothing", 0.0) == 0.0:
+        return HF.cross_entropy(output, label, gamma)
+    return criterion(output, label) * gamma
+
+
+def _mse(criterion, output, target):
+    if isinstance(criterion, torch.nn.MSELoss) and criterion.reduction == "mean":
+        return HF.mse_loss(output, target)
+    return criterion(output, target)
+
+
+def train_tile(loader, epoch, total_epochs, model, device, criterion, optimizer, scheduler, gamma):
+    """Tile training for one epoch (train/train.py:12-48)."""
+    model.train()
+    tile_num = 0
+    train_loss = torch.zeros((), device=device)
+    train_bar = tqdm(loader, desc="tile training")
+    for i, (data, label) in enumerate(train_bar):
+        optimizer.zero_grad()
+        output = model(data.to(device), freeze_bn=True)
+        loss = _ce(criterion, output, label.to(device), gamma)
+        loss.backward()
+        optimizer.step()
+        if _per_step(scheduler):
+            scheduler.step()
+        tile_num += data.size(0)
+        train_loss += loss.detach() * data.size(0)
+    if not (scheduler is None or _per_step(scheduler)):
+        scheduler.step()
+    return float(train_loss.item()) / tile_num
+
+
+def train_image(loader, epoch, total_epochs, model, device, crit_cls, crit_reg, optimizer, scheduler, alpha, beta):
+    """Image-level classification + count regression for one epoch (train/train.py:51-105)."""
+    model.train()
+    acc = torch.zeros((3,), device=device)
+    for i, (data, label_cls, label_num) in enumerate(tqdm(loader, desc="image training")):
+        optimizer.zero_grad()
+        output = model(data.to(device))
+        l_cls = _ce(crit_cls, output[0], label_cls.to(device))
+        l_reg = _mse(crit_reg, output[1].squeeze(), label_num.to(device, dtype=torch.float32))
+        loss = alpha * l_cls + beta * l_reg
+        loss.backward()
+        optimizer.step()
+        if _per_step(scheduler):
+            scheduler.step()
+        acc += torch.stack([l_cls.detach(), l_reg.detach(), loss.detach()]) * data.size(0)
+    if not (scheduler is None or _per_step(scheduler)):
+        scheduler.step()
+    n = len(loader.dataset)
+    c, r, t = (acc / n).tolist()
+    return c, r, t
+
+
+def train_image_cls(loader, epoch, total_epochs, model, device, crit_cls, optimizer, scheduler):
+    """train/train.py:109-137"""
+    model.train()
+    acc = torch.zeros((), device=device)
+    for i, (data, label_cls, label_num) in enumerate(tqdm(loader, desc="image training")):
+        optimizer.zero_grad()
+        output = model(data.to(device))
+        l_cls = _ce(crit_cls, output[0], label_cls.to(device))
+        l_cls.backward()
+        optimizer.step()
+        if _per_step(scheduler):
+            scheduler.step()
+        acc += l_cls.detach() * data.size(0)
+    if not (scheduler is None or _per_step(scheduler)):
+        scheduler.step()
+    return float(acc.item()) / len(loader.dataset)
+
+
+def train_image_reg(loader, epoch, total_epochs, model, device, crit_reg, optimizer, scheduler):
+    """train/train.py:140-169"""
+    model.train()
+    acc = torch.zeros((), device=device)
+    for i, (data, label_cls, label_num) in enumerate(tqdm(loader, desc="image training")):
+        optimizer.zero_grad()
+        output = model(data.to(device))
+        l_reg = _mse(crit_reg, output[1].squeeze(), label_num.to(device, dtype=torch.float32))
+        l_reg.backward()
+        optimizer.step()
+        if _per_step(scheduler):
+            scheduler.step()
+        acc += l_reg.detach() * data.size(0)
+    if not (scheduler is None or _per_step(scheduler)):
+        scheduler.step()
+    return float(acc.item()) / len(loader.dataset)
+
+
+def train_seg(loader, epoch, total_epochs, model, device, optimizer, scheduler):
+    """Segmentation training for one epoch (train/train.py:172-207): loss = Dice(softmax(out)[:,1], mask/255)."""
+    model.train()
+    acc = torch.zeros((), device=device)
+    for i, (image, mask, label) in enumerate(tqdm(loader, desc="segmentation training")):
+        mask = (mask / 255).to(device, dtype=torch.float32)
+        optimizer.zero_grad()
+        output = model(image.to(device)).to(dtype=torch.float32)
+        loss = HF.dice_loss(HF.softmax_channel(output, 1), mask)
+        loss.backward()
+        optimizer.step()
+        if _per_step(scheduler):
+            scheduler.step()
+        acc += loss.detach() * image.size(0)
+    if not (scheduler is None or _per_step(scheduler)):
+        scheduler.step()
+    return float(acc.item()) / len(loader.dataset)

@@ -287,8 +287,14 @@ def categorize(x):
     return 6
 
 
+def _axis_origins(length, interval, size):
+    o = list(range(0, length - size + 1, interval))
+    if o[-1] + size != length:          # the sliding window adds one border-aligned tile (dataset.py:731-732,734-740)
+        o.append(length - size)
+    return o
+
+
 def get_tiles_coords(h, w, interval, size):
-    """dataset/dataset.py:718-742 grid of top-left tile corners."""
-    ys = list(range(0, h - size + 1, interval))
-    xs = list(range(0, w - size + 1, interval))
-    return [(x, y) for x in xs for y in ys]
+    """dataset/dataset.py:718-742: upper-left (row, col) of every tile, row-major, with a final
+    border-aligned row/column when the stride does not land on the edge."""
+    return [(x, y) for x in _axis_origins(h, interval, size) for y in _axis_origins(w, interval, size)]

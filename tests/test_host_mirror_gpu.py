@@ -1,0 +1,151 @@
+"""GPU: the reference-shaped host API (train.train_*, inference.inference_tiles/sample, train.losses)
+driven end to end like the reference drivers drive it, against the CPU oracle on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import inference as I  # noqa: E402
+from cellsegmentation_amd import synth, train as T  # noqa: E402
+from cellsegmentation_amd.model import resnet as R  # noqa: E402
+from oracle import cellseg_oracle as orc  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"), allow_pickle=False)
+
+
+class _Loader(list):
+    """Just enough of a DataLoader: iterable of batches + .dataset + .batch_size."""
+
+    def __init__(self, batches, n, batch_size):
+        super().__init__(batches)
+        self.dataset = range(n)
+        self.batch_size = batch_size
+
+
+def _model(arch, dev):
+    m = {"resnet18": R.MILresnet18, "resnet50": R.MILresnet50}[arch]()
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m.to(dev).set_compute_dtype(torch.float32)
+
+
+def _oracle_sd(arch, trainable):
+    sd = orc.empty_state_dict(arch)
+    synth.fill_state_dict(sd)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and trainable(k):
+            v.requires_grad_()
+    return sd
+
+
+def test_inference_tiles_and_sample_like_train_tile_py(dev):
+    arch, n_img, tiles_per = "resnet18", 6, 9
+    x = synth.normalise(synth.ihc_tiles(n_img * tiles_per, 32, 41))
+    tile_idx = np.repeat(np.arange(n_img), tiles_per).tolist()
+    labels = [0, 2, 0, 1, 5, 0]
+    bs = 16
+    batches = [(x[i:i + bs], torch.zeros(min(bs, len(x) - i))) for i in range(0, len(x), bs)]
+    m = _model(arch, dev)
+    m.setmode("tile")
+    probs = I.inference_tiles(_Loader(batches, len(x), bs), m, dev)
+    ref = orc.tile_probs(_oracle_sd(arch, lambda k: False), x, arch)
+    assert probs.dtype == np.float32 and probs.shape == (len(x),)
+    assert float(np.abs(probs - ref).max()) < 1e-5
+
+    class _Set:
+        tileIDX, got = tile_idx, None
+
+        def __init__(self):
+            self.labels = labels
+
+        def __len__(self):
+            return len(self.tileIDX)
+
+        def make_train_data(self, idxs, ratio):
+            self.got = list(idxs)
+            return 1, 2
+
+    ds = _Set()
+    I.sample(ds, ref, 1, 3, 0.5)          # identical probs into both selections (SURVEY hard part iii)
+    assert ds.got == orc.sample_indices(ref, tile_idx, labels, 1, 3).tolist()
+
+
+def test_train_tile_epoch_matches_oracle(dev):
+    arch, n = "resnet18", 8
+    x = synth.normalise(synth.ihc_tiles(n, 32, 43))
+    y = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    batches = [(x[:4], y[:4]), (x[4:], y[4:])]
+    m = _model(arch, dev)
+    m.setmode("tile")                                        # reference default: encoder frozen
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=5e-4, weight_decay=1e-4)
+    loss = T.train_tile(_Loader(batches, n, 4), 1, 1, m, dev, torch.nn.CrossEntropyLoss(), opt, None, 1.0)
+    sd = _oracle_sd(arch, lambda k: k.startswith("fc_tile"))
+    oopt = torch.optim.Adam([sd["fc_tile.1.weight"], sd["fc_tile.1.bias"]], lr=5e-4, weight_decay=1e-4)
+    tot = 0.0
+    for xb, yb in batches:
+        oopt.zero_grad()
+        l = orc.tile_step_loss(sd, xb, yb, arch)
+        l.backward()
+        oopt.step()
+        tot += l.item() * len(xb)
+    assert abs(loss - tot / n) < 1e-4 * abs(tot / n)
+    assert float((m.fc_tile[1].weight.detach().cpu() - sd["fc_tile.1.weight"].detach()).abs().max()) < 1e-5
+
+
+def test_train_image_step_matches_oracle(dev):
+    arch, n = "resnet18", 4
+    x = synth.normalise(synth.ihc_tiles(n, 96, 45))
+    counts = torch.tensor([0, 3, 12, 40])
+    cls = torch.tensor([orc.categorize(int(c)) for c in counts])
+    m = _model(arch, dev)
+    m.setmode("image")
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, m.parameters()), lr=0.0)
+    c, r, t = T.train_image(_Loader([(x, cls, counts)], n, n), 1, 1, m, dev, torch.nn.CrossEntropyLoss(), torch.nn.MSELoss(), opt, None, 1.0, 1.0)
+    sd = _oracle_sd(arch, lambda k: True)
+    oc, orr, ot = orc.image_step_loss(sd, x, cls, counts, arch)
+    for got, want in ((c, oc.item()), (r, orr.item()), (t, ot.item())):
+        assert abs(got - want) < 2e-4 * abs(want)
+
+
+def test_train_seg_step_matches_oracle(dev):
+    arch, n, size = "resnet18", 2, 75
+    x = synth.normalise(synth.ihc_tiles(n, size, 47))
+    mask = (torch.rand(n, size, size, generator=torch.Generator().manual_seed(1)) > 0.7).to(torch.uint8) * 255
+    m = _model(arch, dev)
+    m.setmode("segment")
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, m.parameters()), lr=0.0)
+    loss = T.train_seg(_Loader([(x, mask, torch.zeros(n))], n, n), 1, 1, m, dev, opt, None)
+    want = orc.seg_step_loss(_oracle_sd(arch, lambda k: False), x, (mask / 255).float(), arch).item()
+    assert abs(loss - want) < 2e-4 * abs(want)
+    # inference_seg 'test' mode returns softmax channel 1
+    m2 = _model(arch, dev)
+    m2.setmode("segment")
+    out = I.inference_seg([x], m2, dev, mode="test")
+    ref = torch.softmax(orc.forward(_oracle_sd(arch, lambda k: False), x, arch, "segment", training=False), 1)[:, 1]
+    assert out.shape == (n, size, size) and float(np.abs(out - ref.numpy()).max()) < 1e-4
+
+
+def test_loss_modules_match_reference_vectors(dev):
+    a, b = torch.from_numpy(GOLD["loss/dice_in"]).to(dev), torch.from_numpy(GOLD["loss/dice_tg"]).to(dev)
+    assert abs(T.DiceLoss()(a, b).item() - float(GOLD["loss/dice_mean"])) < 1e-5
+    assert abs(T.DiceLoss(reduction="sum")(a, b).item() - float(GOLD["loss/dice_sum"])) < 1e-5
+    assert abs(T.DiceLoss()(a[0], b[0]).item() - float(GOLD["loss/dice_2d"])) < 1e-5
+    x, t = torch.from_numpy(GOLD["loss/wmse_in"]).to(dev), torch.from_numpy(GOLD["loss/wmse_tg"]).to(dev)
+    assert abs(T.WeightedMSELoss()(x, t).item() - float(GOLD["loss/wmse_mean"])) < 1e-4 * float(GOLD["loss/wmse_mean"])
+    assert abs(T.WeightedMSELoss(reduction="sum")(x, t).item() - float(GOLD["loss/wmse_sum"])) < 1e-4 * float(GOLD["loss/wmse_sum"])
+    assert abs(T.MSELoss()(x, t).item() - float(GOLD["loss/mse_mean"])) < 1e-4 * float(GOLD["loss/mse_mean"])
+    # gradients of the dice modules against autograd on the oracle formula
+    p = a.clone().requires_grad_()
+    T.DiceLoss()(p, b).backward()
+    pc = a.cpu().clone().requires_grad_()
+    orc.dice_loss(pc, b.cpu()).backward()
+    assert float((p.grad.cpu() - pc.grad).abs().max()) < 1e-6
+    d = T.dice_coef(a, b)
+    assert float((d.cpu() - orc.dice_coef(a.cpu(), b.cpu())).abs().max()) < 1e-5

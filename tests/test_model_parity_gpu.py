@@ -19,6 +19,9 @@ GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vect
 FACT = {"resnet18": R.MILresnet18, "resnet34": R.MILresnet34, "resnet50": R.MILresnet50}
 RTOL = 1e-4          # logits / loss / probabilities (north_star tolerance)
 GTOL = 5e-3          # gradients: ~3x the reference's own fp32-vs-fp64 noise (1.5e-3, tests/golden/measure_fp32_noise.py)
+# train-mode BN makes gradients far worse conditioned (36 samples/channel in layer4 at 96x96): measured noise of the
+# reference's own fp32 path vs fp64 truth, tests/golden/measure_fp32_noise.py; the band is 3x that.
+IMAGE_GRAD_NOISE = {"resnet18/image299": 5.9e-3, "resnet50/image96": 7.0e-2}
 
 
 def build(arch, dev, dtype=torch.float32):
@@ -158,7 +161,7 @@ def test_image_mode_matches_reference_fp32(arch, size, dev):
         if e > 1e-5:
             errs.append(f"{k} rel err {e:.2e}")
     assert int(bufs["bn1.num_batches_tracked"]) == 1
-    check_grads(tag, dict(m.named_parameters()), errs, GTOL)
+    check_grads(tag, dict(m.named_parameters()), errs, 3 * IMAGE_GRAD_NOISE[tag])
     # eval-mode inference (inference.py:46-101)
     m.eval()
     with torch.no_grad():
