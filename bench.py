@@ -62,7 +62,13 @@ def kernel_name(kind, g, dtype):
     else:
         M, nout = g["N"] * g["H"] * g["W"], g["C"]
     bm, bn = K.igemm_tile(M, nout)
-    return f"igemm_kernel<{dt},{bm},{bn}>"
+    if kind == "dgrad" and g["stride"] > 1:
+        mode = 2                                   # strided data-gradient: general addressing
+    elif g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0:
+        mode = 0                                   # pure GEMM rows
+    else:
+        mode = 1                                   # tap-validity bitmask
+    return f"igemm_kernel<{dt},{bm},{bn},{mode}>"
 
 
 def roofline_from(records, steps, dtype):

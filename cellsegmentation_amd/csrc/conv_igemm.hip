@@ -63,7 +63,10 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN>
+// MODE 0: 1x1, stride 1, no padding  -> plain GEMM rows (no tap logic at all)
+// MODE 1: any filter with div == 1     -> per-row tap-validity bitmask + base offset, 1 test + 1 add per load
+// MODE 2: div > 1 (strided data-gradient): general coordinate arithmetic per load
+template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     constexpr int CE = Elem<T>::kChunk;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -84,22 +87,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     // ---- per-thread gather bookkeeping: fixed rows, walking (kh,kw,cc) ----
     const int lc = tid & 7;    // chunk column inside the K-step
     const int lr = tid >> 3;   // 0..31
-    long long rowbase[AI];     // pixel index of (n,0,0) in the source tensor, or -1 if row invalid
+    // MODE 0/1: rbase = element offset of the row's tap-(0,0) source pixel, vmask bit t = tap t is in bounds
+    // MODE 2  : rbase = pixel index of (n,0,0) or -1; ty/tx = destination coordinate terms
+    long long rbase[AI];
+    unsigned long long vmask[AI];
     int ty[AI], tx[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const long long m = m0 + lr + 32 * i;
+        rbase[i] = -1; vmask[i] = 0; ty[i] = 0; tx[i] = 0;
         if (m < p.M) {
-            const long long img = m / ((long long)p.DH * p.DW);
-            const int rem = (int)(m - img * (long long)p.DH * p.DW);
-            const int dy = rem / p.DW;
-            const int dx = rem - dy * p.DW;
-            rowbase[i] = img * (long long)p.SH * p.SW;
-            ty[i] = dy * p.mul + p.off0;
-            tx[i] = dx * p.mul + p.off0;
-        } else {
-            rowbase[i] = -1;
-            ty[i] = 0; tx[i] = 0;
+            if constexpr (MODE == 0) {
+                rbase[i] = m * p.SC;
+                vmask[i] = 1;
+            } else {
+                const long long img = m / ((long long)p.DH * p.DW);
+                const int rem = (int)(m - img * (long long)p.DH * p.DW);
+                const int dy = rem / p.DW;
+                const int dx = rem - dy * p.DW;
+                const int y0 = dy * p.mul + p.off0;
+                const int x0 = dx * p.mul + p.off0;
+                if constexpr (MODE == 1) {
+                    rbase[i] = ((img * p.SH + y0) * (long long)p.SW + x0) * p.SC;
+                    unsigned long long mk = 0;
+                    for (int a = 0; a < p.R; ++a) {
+                        const int y = y0 + p.sgn * a;
+                        if (y < 0 || y >= p.SH) continue;
+                        for (int b = 0; b < p.S; ++b) {
+                            const int x = x0 + p.sgn * b;
+                            if (x >= 0 && x < p.SW) mk |= 1ull << (a * p.S + b);
+                        }
+                    }
+                    vmask[i] = mk;
+                } else {
+                    rbase[i] = img * (long long)p.SH * p.SW;
+                    ty[i] = y0; tx[i] = x0;
+                }
+            }
         }
     }
     // walking position of this thread's chunk column in K space
@@ -116,24 +140,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     uint4 ra[AI], rb[BI];
     auto gload = [&]() {
         const bool qok = q < p.Qtot;
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (qok && rowbase[i] >= 0) {
-                int y = ty[i] + p.sgn * kh;
-                int x = tx[i] + p.sgn * kw;
-                bool ok = (y >= 0) && (x >= 0);
-                if (p.div > 1) {
-                    ok = ok && (y % p.div == 0) && (x % p.div == 0);
-                    y /= p.div; x /= p.div;
-                }
-                ok = ok && (y < p.SH) && (x < p.SW);
-                if (ok) {
-                    const long long pix = rowbase[i] + (long long)y * p.SW + x;
-                    v = *reinterpret_cast<const uint4*>(src + pix * p.SC + cc * CE);
-                }
+            for (int i = 0; i < AI; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (qok && vmask[i]) v = *reinterpret_cast<const uint4*>(src + rbase[i] + q * CE);
+                ra[i] = v;
             }
-            ra[i] = v;
+        } else if constexpr (MODE == 1) {
+            const int t = kh * p.S + kw;
+            const long long toff = ((long long)(p.sgn * kh) * p.SW + p.sgn * kw) * p.SC + cc * CE;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (qok && ((vmask[i] >> t) & 1ull)) v = *reinterpret_cast<const uint4*>(src + rbase[i] + toff);
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (qok && rbase[i] >= 0) {
+                    int y = ty[i] + p.sgn * kh;
+                    int x = tx[i] + p.sgn * kw;
+                    bool ok = (y >= 0) && (x >= 0) && (y % p.div == 0) && (x % p.div == 0);
+                    y /= p.div; x /= p.div;
+                    ok = ok && (y < p.SH) && (x < p.SW);
+                    if (ok) {
+                        const long long pix = rbase[i] + (long long)y * p.SW + x;
+                        v = *reinterpret_cast<const uint4*>(src + pix * p.SC + cc * CE);
+                    }
+                }
+                ra[i] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
@@ -145,11 +184,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     };
     auto advance = [&]() {
         q += 8;
-        cc += 8;
-        while (cc >= p.SCc) {
-            cc -= p.SCc;
-            ++kw;
-            if (kw == p.S) { kw = 0; ++kh; }
+        if constexpr (MODE != 0) {
+            cc += 8;
+            while (cc >= p.SCc) {
+                cc -= p.SCc;
+                ++kw;
+                if (kw == p.S) { kw = 0; ++kh; }
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -316,13 +357,23 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+int igemm_mode(const IgemmParams& p) {
+    if (p.div > 1) return 2;
+    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0) return 0;
+    return p.R * p.S <= 64 ? 1 : 2;
+}
+
 template <typename T, int BM, int BN>
 int launch_igemm(const IgemmParams& p, hipStream_t st) {
     constexpr size_t stage_bytes = 2ull * (BM + BN) * 8 * 16;
     constexpr size_t epi_bytes = (size_t)BM * BN * 4;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.NOUT + BN - 1) / BN), 1);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), grid, dim3(256), lds, st, p);
+    switch (igemm_mode(p)) {
+        case 0: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p); break;
+        case 1: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p); break;
+        default: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p); break;
+    }
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
