@@ -34,6 +34,7 @@ _SIGNATURES = {
     "cs_conv2d_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "cs_conv2d_stats_workspace": (c_size_t, [c_longlong, c_int]),
     "cs_igemm_tile": (c_int, [c_longlong, c_int]),
+    "cs_set_igemm_path": (c_int, [c_int]),
     "cs_conv2d_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cs_conv2d_wgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, _P]),
     "cs_wgrad_finalize": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),

@@ -40,6 +40,7 @@ struct IgemmParams {
     int mul, div, off0, sgn;
     int act;
     long long M;      // N*DH*DW
+    long long src_pixels;   // N*SH*SW
     int Qtot;         // R*S*SCc
     int SCc;          // SC / chunk
 };
@@ -62,6 +63,112 @@ template <> struct Mma<float> {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
     }
 };
+
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* smem_raw,
+                                               long long m0, int n0) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    // ---- epilogue: accumulators -> LDS fp32 [BM][BN] (aliases the staging buffers) ----
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int col = wn * (BN / 2) + j * 32 + l31;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int CG = BN / 8;              // 8-channel groups per tile row
+    constexpr int ITERS = BM * BN / 8 / 256;
+    const int cg = tid % CG;
+    const int o = n0 + cg * 8;
+    const bool ook = o < p.NOUT;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = (p.scale && ook) ? p.scale[o + e] : 1.f;
+        sh[e] = (p.shift && ook) ? p.shift[o + e] : 0.f;
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    const T* __restrict__ msk = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = it * (256 / CG) + tid / CG;
+        const long long m = m0 + row;
+        if (m < p.M && ook) {
+            float v[8];
+            const float4 c0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+            const float4 c1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            const long long off = m * p.NOUT + o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (res) {
+                float r8[8];
+                load8<T>(res + off, r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r8[e];
+            }
+            if (p.act == CS_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (p.act == CS_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+            }
+            if (msk) {
+                float k8[8];
+                load8<T>(msk + off, k8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
+            }
+            store8<T>(dst + off, v);
+            if (p.slab) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // statistics are those of the STORED (rounded) values
+                    const float w = to_f32<T>(from_f32<T>(v[e]));
+                    s1[e] += w;
+                    s2[e] += w * w;
+                }
+            }
+        }
+    }
+    if (p.slab) {
+        // fold the 256/CG threads that own the same 8 channels through LDS (Cs is dead now)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);        // [256][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < CG && ook) {
+            float t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+            for (int r = tid; r < 256; r += CG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t1[e] += red[r * 16 + e]; t2[e] += red[r * 16 + 8 + e]; }
+            }
+            float* row = p.slab + (long long)blockIdx.x * 2 * p.NOUT;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { row[o + e] = t1[e]; row[p.NOUT + o + e] = t2[e]; }
+        }
+    }
+}
 
 // MODE 0: 1x1, stride 1, no padding  -> plain GEMM rows (no tap logic at all)
 // MODE 1: any filter with div == 1     -> per-row tap-validity bitmask + base offset, 1 test + 1 add per load
@@ -237,101 +344,177 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS fp32 [BM][BN] (aliases the staging buffers) ----
-    float* Cs = reinterpret_cast<float*>(smem_raw);
+    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (default): global -> LDS with `buffer_load_dwordx4 ... lds`, no staging VGPRs and
+// no ds_write pass (the register-staged version spent ~416 LDS-store cycles per 512 MFMA cycles).
+//  * one wave-instruction fills 8 tile rows x 128 B = 1 KiB of contiguous LDS (lane-linear
+//    destination); the XOR swizzle is therefore applied to the per-lane SOURCE chunk, the MFMA
+//    operand reads use the same involution (guide rule 21);
+//  * padding taps, M/N tails and K tails are lanes whose buffer offset is out of range: the
+//    hardware range check returns zeros, which the DMA writes to LDS -- no branches, no masks;
+//  * needs every operand < 2 GiB (32-bit buffer offsets); larger tensors use the register path.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 8;  // uint4 per stage
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* smem = reinterpret_cast<uint4*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, wgt_bytes, 0x00020000);
+
+    const int lr = tid >> 3;                       // tile row of DMA instruction 0 (+32 per instruction)
+    const int lc = (tid & 7) ^ ((lr >> 1) & 7);    // LOGICAL chunk column this lane fetches into physical slot tid&7
+    int rbase[AI];                                 // byte offset of the row's tap-(0,0) pixel (MODE 0/1) / pixel index (MODE 2)
+    unsigned long long vmask[AI];
+    int ty[AI], tx[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const long long m = m0 + lr + 32 * i;
+        rbase[i] = 0; vmask[i] = 0; ty[i] = 0; tx[i] = 0;
+        if (m < p.M) {
+            if constexpr (MODE == 0) {
+                rbase[i] = (int)(m * p.SC * ES);
+                vmask[i] = 1;
+            } else {
+                const long long img = m / ((long long)p.DH * p.DW);
+                const int rem = (int)(m - img * (long long)p.DH * p.DW);
+                const int dy = rem / p.DW;
+                const int dx = rem - dy * p.DW;
+                const int y0 = dy * p.mul + p.off0;
+                const int x0 = dx * p.mul + p.off0;
+                if constexpr (MODE == 1) {
+                    rbase[i] = (int)(((img * p.SH + y0) * (long long)p.SW + x0) * p.SC * ES);
+                    unsigned long long mk = 0;
+                    for (int a = 0; a < p.R; ++a) {
+                        const int y = y0 + p.sgn * a;
+                        if (y < 0 || y >= p.SH) continue;
+                        for (int b = 0; b < p.S; ++b) {
+                            const int x = x0 + p.sgn * b;
+                            if (x >= 0 && x < p.SW) mk |= 1ull << (a * p.S + b);
+                        }
+                    }
+                    vmask[i] = mk;
+                } else {
+                    rbase[i] = (int)(img * (long long)p.SH * p.SW);
+                    vmask[i] = 1;
+                    ty[i] = y0; tx[i] = x0;
+                }
+            }
+        }
+    }
+    int q = lc;
+    int tap = q / p.SCc;
+    int cc = q - tap * p.SCc;
+    int kh = tap / p.S;
+    int kw = tap - kh * p.S;
+    const unsigned wrow_bytes = (unsigned)p.Qtot * 16u;
+    unsigned bbase[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int o = n0 + lr + 32 * j;
+        bbase[j] = o < p.NOUT ? (unsigned)o * wrow_bytes : OOB;
+    }
+
+    auto issue = [&](int buf) {
+        unsigned char* As = smem_raw + (size_t)buf * STAGE * 16;
+        unsigned char* Bs = As + BM * 128;
+        const bool qok = q < p.Qtot;
+        unsigned va[AI];
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) va[i] = (qok && vmask[i]) ? (unsigned)(rbase[i] + q * 16) : OOB;
+        } else if constexpr (MODE == 1) {
+            const int t = kh * p.S + kw;
+            const int toff = ((p.sgn * kh) * p.SW + p.sgn * kw) * p.SC * ES + cc * 16;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) va[i] = (qok && ((vmask[i] >> t) & 1ull)) ? (unsigned)(rbase[i] + toff) : OOB;
+        } else {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                unsigned v = OOB;
+                if (qok && vmask[i]) {
+                    int y = ty[i] + p.sgn * kh;
+                    int x = tx[i] + p.sgn * kw;
+                    bool ok = (y >= 0) && (x >= 0) && (y % p.div == 0) && (x % p.div == 0);
+                    y /= p.div; x /= p.div;
+                    ok = ok && (y < p.SH) && (x < p.SW);
+                    if (ok) v = (unsigned)(((rbase[i] + y * p.SW + x) * p.SC) * ES + cc * 16);
+                }
+                va[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (8 * wave + 32 * i) * 128), 16,
+                                                     (int)va[i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const unsigned vb = (qok && bbase[j] != OOB) ? bbase[j] + (unsigned)q * 16u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (8 * wave + 32 * j) * 128), 16,
+                                                     (int)vb, 0, 0, 0);
+        }
+        // advance this lane's K position by one K-step (8 chunks)
+        q += 8;
+        if constexpr (MODE != 0) {
+            cc += 8;
+            while (cc >= p.SCc) {
+                cc -= p.SCc;
+                ++kw;
+                if (kw == p.S) { kw = 0; ++kh; }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int col = wn * (BN / 2) + j * 32 + l31;
-                Cs[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int CG = BN / 8;              // 8-channel groups per tile row
-    constexpr int ITERS = BM * BN / 8 / 256;
-    const int cg = tid % CG;
-    const int o = n0 + cg * 8;
-    const bool ook = o < p.NOUT;
-    float sc[8], sh[8];
+    const int nk = (p.Qtot + 7) / 8;
+    issue(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile ks have landed
+        __syncthreads();                                    // ... and everybody else's; also frees the other buffer
+        if (ks + 1 < nk) issue((ks + 1) & 1);
+        const uint4* As = smem + (ks & 1) * STAGE;
+        const uint4* Bs = As + BM * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = (p.scale && ook) ? p.scale[o + e] : 1.f;
-        sh[e] = (p.shift && ook) ? p.shift[o + e] : 0.f;
-    }
-    float s1[8], s2[8];
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = 2 * kk + hh;
+            uint4 a[TM], b[TN];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
-    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-    const T* __restrict__ msk = reinterpret_cast<const T*>(p.mask);
+            for (int i = 0; i < TM; ++i) a[i] = As[swz(wm * (BM / 2) + i * 32 + l31, c)];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = it * (256 / CG) + tid / CG;
-        const long long m = m0 + row;
-        if (m < p.M && ook) {
-            float v[8];
-            const float4 c0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
-            const float4 c1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
-            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
-            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-            const long long off = m * p.NOUT + o;
+            for (int j = 0; j < TN; ++j) b[j] = Bs[swz(wn * (BN / 2) + j * 32 + l31, c)];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-            if (res) {
-                float r8[8];
-                load8<T>(res + off, r8);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r8[e];
-            }
-            if (p.act == CS_ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else if (p.act == CS_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
-            }
-            if (msk) {
-                float k8[8];
-                load8<T>(msk + off, k8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
-            }
-            store8<T>(dst + off, v);
-            if (p.slab) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    // statistics are those of the STORED (rounded) values
-                    const float w = to_f32<T>(from_f32<T>(v[e]));
-                    s1[e] += w;
-                    s2[e] += w * w;
-                }
-            }
+                for (int j = 0; j < TN; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
         }
     }
-    if (p.slab) {
-        // fold the 256/CG threads that own the same 8 channels through LDS (Cs is dead now)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem_raw);        // [256][16]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
-        __syncthreads();
-        if (tid < CG && ook) {
-            float t1[8], t2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-            for (int r = tid; r < 256; r += CG) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { t1[e] += red[r * 16 + e]; t2[e] += red[r * 16 + 8 + e]; }
-            }
-            float* row = p.slab + (long long)blockIdx.x * 2 * p.NOUT;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { row[o + e] = t1[e]; row[p.NOUT + o + e] = t2[e]; }
-        }
-    }
+    __syncthreads();
+    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0);
 }
 
 // Fold the per-workgroup partial rows: out[c] += sum_r slab[r][c] for c < ncols (row stride = stride).
@@ -357,6 +540,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
+
 int igemm_mode(const IgemmParams& p) {
     if (p.div > 1) return 2;
     if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0) return 0;
@@ -369,10 +554,22 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     constexpr size_t epi_bytes = (size_t)BM * BN * 4;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.NOUT + BN - 1) / BN), 1);
-    switch (igemm_mode(p)) {
-        case 0: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p); break;
-        case 1: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p); break;
-        default: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p); break;
+    const unsigned long long src_bytes = (unsigned long long)p.src_pixels * p.SC * sizeof(T);
+    const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.Qtot * 16ull;
+    const bool dma = g_igemm_path == 0 && src_bytes < 0x80000000ull && wgt_bytes < 0x80000000ull;
+    const int mode = igemm_mode(p);
+    if (dma) {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
+            case 1: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
+            default: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
+        }
+    } else {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p); break;
+            case 1: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p); break;
+            default: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p); break;
+        }
     }
     CS_LAUNCH_CHECK();
     return CS_OK;
@@ -428,6 +625,7 @@ int check_geom(const CsConvGeom* g, int dtype) {
 }  // namespace
 
 extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_out); }
+extern "C" int cs_set_igemm_path(int path) { const int old = g_igemm_path; g_igemm_path = path; return old; }
 
 extern "C" size_t cs_conv2d_stats_workspace(long long M, int n_out) {
     const int bm = igemm_tile(M, n_out) / 1000;
@@ -452,6 +650,7 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     p.mul = g->stride; p.div = 1; p.off0 = -g->pad; p.sgn = 1;
     p.act = act;
     p.M = (long long)g->N * g->P * g->Q;
+    p.src_pixels = (long long)g->N * g->H * g->W;
     p.SCc = g->C / ce;
     p.Qtot = g->R * g->S * p.SCc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -477,6 +676,7 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     p.mul = 1; p.div = g->stride; p.off0 = g->pad; p.sgn = -1;
     p.act = CS_ACT_NONE;
     p.M = (long long)g->N * g->H * g->W;
+    p.src_pixels = (long long)g->N * g->P * g->Q;
     p.SCc = g->K / ce;
     p.Qtot = g->R * g->S * p.SCc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

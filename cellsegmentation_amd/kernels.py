@@ -128,6 +128,11 @@ def _stats_ws(M, n_out, device):
     return torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
 
 
+def set_igemm_path(path):
+    """0 = LDS-DMA staging (default), 1 = register staging. Returns the previous value."""
+    return _lib.load().cs_set_igemm_path(int(path))
+
+
 def igemm_tile(M, n_out):
     """(BM, BN) the fwd/dgrad dispatcher picks."""
     v = _lib.load().cs_igemm_tile(int(M), int(n_out))

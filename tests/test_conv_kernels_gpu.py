@@ -50,9 +50,16 @@ def _relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+@pytest.fixture(params=[0, 1], ids=["lds_dma", "reg_staged"])
+def igemm_path(request):
+    old = K.set_igemm_path(request.param)
+    yield request.param
+    K.set_igemm_path(old)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_conv_fwd_dgrad_wgrad(shape, dtype, dev):
+def test_conv_fwd_dgrad_wgrad(shape, dtype, dev, igemm_path):
     N, H, W, Cin, Cout, R, s, p = shape
     g = torch.Generator().manual_seed(1234 + Cin * 7 + Cout)
     x = _q(torch.randn((N, Cin, H, W), generator=g), dtype)

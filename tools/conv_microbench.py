@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Time individual conv-family launches (HIP events) on chosen ResNet-50 shapes; also the target
+program for `rocprofv3 --pmc ...` counter passes.   python tools/conv_microbench.py [shape ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cellsegmentation_amd import kernels as K  # noqa: E402
+
+#  name: (N, H, W, Cin, Cout, R, stride, pad)
+SHAPES = {
+    "l1_3x3": (64, 75, 75, 64, 64, 3, 1, 1),
+    "l2_3x3": (64, 38, 38, 128, 128, 3, 1, 1),
+    "l3_3x3": (64, 19, 19, 256, 256, 3, 1, 1),
+    "l4_3x3": (64, 10, 10, 512, 512, 3, 1, 1),
+    "l1_1x1_64_256": (64, 75, 75, 64, 256, 1, 1, 0),
+    "l1_1x1_256_64": (64, 75, 75, 256, 64, 1, 1, 0),
+    "l3_1x1_1024_256": (64, 19, 19, 1024, 256, 1, 1, 0),
+    "l2_3x3_s2": (64, 75, 75, 128, 128, 3, 2, 1),
+    "dec_3x3_2048_1024": (8, 19, 19, 2048, 1024, 3, 1, 1),
+}
+
+
+def main():
+    names = sys.argv[1:] or list(SHAPES)
+    iters = int(os.environ.get("ITERS", "20"))
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if os.environ.get("DTYPE", "bf16") == "bf16" else torch.float32
+    K.set_igemm_path(int(os.environ.get("IGEMM_PATH", "0")))
+    for name in names:
+        N, H, W, C, Kc, R, s, p = SHAPES[name]
+        g = K.make_geom(N, H, W, C, Kc, R, R, s, p)
+        x = torch.randn((N, H, W, C), device=dev).to(dt)
+        w = torch.randn((Kc, C, R, R), device=dev) * (1.0 / (C * R * R) ** 0.5)
+        wk, wc = K.weight_prep(w, None, dt, C, Kc, True, True)
+        dy = torch.randn((N, g.P, g.Q, Kc), device=dev).to(dt)
+        raw = torch.zeros((Kc, R, R, C), dtype=torch.float32, device=dev)
+        shift = torch.zeros((Kc,), device=dev)
+        flops = 2.0 * N * g.P * g.Q * Kc * C * R * R
+        res = {}
+        for kind, fn in (("fwd", lambda: K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_RELU)),
+                         ("dgrad", lambda: K.conv_dgrad(g, dy, wc, None, x)),
+                         ("wgrad", lambda: K.conv_wgrad(g, x, dy, raw))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(iters):
+                fn()
+            s1.record()
+            torch.cuda.synchronize()
+            ms = s0.elapsed_time(s1) / iters
+            res[kind] = (ms, flops / ms / 1e9)
+        io_mb = (x.numel() + dy.numel()) * x.element_size() / 1e6
+        print(f"{name:20s} " + "  ".join(f"{k}: {v[0] * 1e3:7.1f} us {v[1]:7.1f} TF" for k, v in res.items()) + f"   in+out {io_mb:6.1f} MB", flush=True)
+
+
+if __name__ == "__main__":
+    main()
