@@ -54,21 +54,20 @@ def conv_flops(g):
 
 
 def kernel_name(kind, g, dtype):
+    """Name of the kernel instantiation the C dispatcher picks for this launch (mirrors conv_igemm.hip)."""
     dt = "bf16" if dtype == torch.bfloat16 else "f32"
     if kind == "wgrad":
         return f"wgrad_kernel<{dt},{128 if g['K'] > 64 else 64},128>"
     if kind == "fwd":
-        M, nout = g["N"] * g["P"] * g["Q"], g["K"]
+        M, nout, suffix = g["N"] * g["P"] * g["Q"], g["K"], ""
     else:
-        M, nout = g["N"] * g["H"] * g["W"], g["C"]
+        M, nout, suffix = g["N"] * g["H"] * g["W"], g["C"], ""
+        if g["stride"] > 1:                        # one stride-1 launch per destination parity class
+            M = M // (g["stride"] ** 2)
+            suffix = f" x{g['stride'] ** 2} parity classes"
     bm, bn = K.igemm_tile(M, nout)
-    if kind == "dgrad" and g["stride"] > 1:
-        mode = 2                                   # strided data-gradient: general addressing
-    elif g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0:
-        mode = 0                                   # pure GEMM rows
-    else:
-        mode = 1                                   # tap-validity bitmask
-    return f"igemm_kernel<{dt},{bm},{bn},{mode}>"
+    mode = 0 if (g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0) else 1
+    return f"igemm_dma_kernel<{dt},{bm},{bn},{mode}>{suffix}"
 
 
 def roofline_from(records, steps, dtype):

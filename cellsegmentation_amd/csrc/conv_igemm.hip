@@ -37,11 +37,17 @@ struct IgemmParams {
     int DH, DW;       // destination spatial extents
     int NOUT;         // destination channels
     int R, S;
-    int mul, div, off0, sgn;
+    int mul, div, off0, off0x, sgn;   // off0 = y offset, off0x = x offset
     int act;
+    // weight-tap walk: filter tap of loop tap (kh,kw) = (wk0y + wkstep*kh, wk0x + wkstep*kw) in an S_full-wide filter
+    int wk0y, wk0x, wkstep, S_full;
+    // destination sub-grid (strided data-gradient parity classes): pixel (n, a*dst_step+dst_oy, b*dst_step+dst_ox) of a
+    // DHF x DWF tensor; dst_step == 1 means rows map to pixels one-to-one
+    int dst_step, dst_oy, dst_ox, DHF, DWF;
     long long M;      // N*DH*DW
     long long src_pixels;   // N*SH*SW
-    int Qtot;         // R*S*SCc
+    int Qtot;         // R*S*SCc (taps walked by this launch)
+    int wrow_chunks;  // chunks per weight row (full filter)
     int SCc;          // SC / chunk
 };
 
@@ -114,7 +120,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
             const float4 c1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
             v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
             v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-            const long long off = m * p.NOUT + o;
+            long long dpix = m;
+            if (p.dst_step != 1) {
+                const long long img = m / ((long long)p.DH * p.DW);
+                const int rem = (int)(m - img * (long long)p.DH * p.DW);
+                const int a = rem / p.DW;
+                const int b = rem - a * p.DW;
+                dpix = (img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox;
+            }
+            const long long off = dpix * p.NOUT + o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
             if (res) {
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                 const int dy = rem / p.DW;
                 const int dx = rem - dy * p.DW;
                 const int y0 = dy * p.mul + p.off0;
-                const int x0 = dx * p.mul + p.off0;
+                const int x0 = dx * p.mul + p.off0x;
                 if constexpr (MODE == 1) {
                     rbase[i] = ((img * p.SH + y0) * (long long)p.SW + x0) * p.SC;
                     unsigned long long mk = 0;
@@ -242,9 +256,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
     const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
-    const long long wrow_elems = (long long)p.Qtot * CE;
+    const long long wrow_elems = (long long)p.wrow_chunks * CE;
 
     uint4 ra[AI], rb[BI];
+    auto wq = [&]() -> int {      // chunk index inside a weight row for the current (kh,kw,cc)
+        if constexpr (MODE == 0) return q;
+        return ((p.wk0y + p.wkstep * kh) * p.S_full + p.wk0x + p.wkstep * kw) * p.SCc + cc;
+    };
     auto gload = [&]() {
         const bool qok = q < p.Qtot;
         if constexpr (MODE == 0) {
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         for (int j = 0; j < BI; ++j) {
             uint4 v = make_uint4(0, 0, 0, 0);
             const int o = n0 + lr + 32 * j;
-            if (qok && o < p.NOUT) v = *reinterpret_cast<const uint4*>(wgt + (long long)o * wrow_elems + (long long)q * CE);
+            if (qok && o < p.NOUT) v = *reinterpret_cast<const uint4*>(wgt + (long long)o * wrow_elems + (long long)wq() * CE);
             rb[j] = v;
         }
     };
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
                 const int dy = rem / p.DW;
                 const int dx = rem - dy * p.DW;
                 const int y0 = dy * p.mul + p.off0;
-                const int x0 = dx * p.mul + p.off0;
+                const int x0 = dx * p.mul + p.off0x;
                 if constexpr (MODE == 1) {
                     rbase[i] = (int)(((img * p.SH + y0) * (long long)p.SW + x0) * p.SC * ES);
                     unsigned long long mk = 0;
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
     int cc = q - tap * p.SCc;
     int kh = tap / p.S;
     int kw = tap - kh * p.S;
-    const unsigned wrow_bytes = (unsigned)p.Qtot * 16u;
+    const unsigned wrow_bytes = (unsigned)p.wrow_chunks * 16u;
     unsigned bbase[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -465,9 +483,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
         for (int i = 0; i < AI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (8 * wave + 32 * i) * 128), 16,
                                                      (int)va[i], 0, 0, 0);
+        int wqv = q;
+        if constexpr (MODE != 0) wqv = ((p.wk0y + p.wkstep * kh) * p.S_full + p.wk0x + p.wkstep * kw) * p.SCc + cc;
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            const unsigned vb = (qok && bbase[j] != OOB) ? bbase[j] + (unsigned)q * 16u : OOB;
+            const unsigned vb = (qok && bbase[j] != OOB) ? bbase[j] + (unsigned)wqv * 16u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (8 * wave + 32 * j) * 128), 16,
                                                      (int)vb, 0, 0, 0);
         }
@@ -544,7 +564,7 @@ int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always registe
 
 int igemm_mode(const IgemmParams& p) {
     if (p.div > 1) return 2;
-    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0) return 0;
+    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0 && p.off0x == 0 && p.wkstep == 1 && p.dst_step == 1) return 0;
     return p.R * p.S <= 64 ? 1 : 2;
 }
 
@@ -555,7 +575,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.NOUT + BN - 1) / BN), 1);
     const unsigned long long src_bytes = (unsigned long long)p.src_pixels * p.SC * sizeof(T);
-    const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.Qtot * 16ull;
+    const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.wrow_chunks * 16ull;
     const bool dma = g_igemm_path == 0 && src_bytes < 0x80000000ull && wgt_bytes < 0x80000000ull;
     const int mode = igemm_mode(p);
     if (dma) {
@@ -647,12 +667,15 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     p.SH = g->H; p.SW = g->W; p.SC = g->C;
     p.DH = g->P; p.DW = g->Q; p.NOUT = g->K;
     p.R = g->R; p.S = g->S;
-    p.mul = g->stride; p.div = 1; p.off0 = -g->pad; p.sgn = 1;
+    p.mul = g->stride; p.div = 1; p.off0 = -g->pad; p.off0x = -g->pad; p.sgn = 1;
+    p.wk0y = 0; p.wk0x = 0; p.wkstep = 1; p.S_full = g->S;
+    p.dst_step = 1; p.dst_oy = 0; p.dst_ox = 0; p.DHF = g->P; p.DWF = g->Q;
     p.act = act;
     p.M = (long long)g->N * g->P * g->Q;
     p.src_pixels = (long long)g->N * g->H * g->W;
     p.SCc = g->C / ce;
     p.Qtot = g->R * g->S * p.SCc;
+    p.wrow_chunks = p.Qtot;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == CS_F32 ? dispatch_igemm<float>(p, nullptr, stats, st) : dispatch_igemm<bf16_t>(p, nullptr, stats, st);
 }
@@ -673,14 +696,46 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     p.SH = g->P; p.SW = g->Q; p.SC = g->K;
     p.DH = g->H; p.DW = g->W; p.NOUT = g->C;
     p.R = g->R; p.S = g->S;
-    p.mul = 1; p.div = g->stride; p.off0 = g->pad; p.sgn = -1;
+    p.mul = 1; p.div = g->stride; p.off0 = g->pad; p.off0x = g->pad; p.sgn = -1;
+    p.wk0y = 0; p.wk0x = 0; p.wkstep = 1; p.S_full = g->S;
+    p.dst_step = 1; p.dst_oy = 0; p.dst_ox = 0; p.DHF = g->H; p.DWF = g->W;
     p.act = CS_ACT_NONE;
     p.M = (long long)g->N * g->H * g->W;
     p.src_pixels = (long long)g->N * g->P * g->Q;
     p.SCc = g->K / ce;
     p.Qtot = g->R * g->S * p.SCc;
+    p.wrow_chunks = p.Qtot;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == CS_F32 ? dispatch_igemm<float>(p, colsum, nullptr, st) : dispatch_igemm<bf16_t>(p, colsum, nullptr, st);
+    if (g->stride == 1 || g->R * g->S > 64)
+        return dtype == CS_F32 ? dispatch_igemm<float>(p, colsum, nullptr, st) : dispatch_igemm<bf16_t>(p, colsum, nullptr, st);
+    // Strided data-gradient = stride^2 independent stride-1 problems, one per residue class of the
+    // destination coordinate: class (py,px) owns pixels (a*s+py, b*s+px) and only the filter taps
+    // kh == (py+pad) mod s (same for kw), for which the source row is a + (py+pad-kh)/s.  Classes without
+    // taps still run (zero K-steps) so that `add`/`mask` are applied and dx is fully written.
+    const int sd = g->stride;
+    for (int py = 0; py < sd; ++py) {
+        for (int px = 0; px < sd; ++px) {
+            IgemmParams c = p;
+            const int kh0 = (py + g->pad) % sd, kw0 = (px + g->pad) % sd;
+            const int nj = kh0 < g->R ? (g->R - kh0 + sd - 1) / sd : 0;
+            const int ni = kw0 < g->S ? (g->S - kw0 + sd - 1) / sd : 0;
+            c.DH = (g->H - py + sd - 1) / sd;
+            c.DW = (g->W - px + sd - 1) / sd;
+            if (c.DH <= 0 || c.DW <= 0) continue;
+            c.div = 1; c.mul = 1; c.sgn = -1;
+            c.off0 = (py + g->pad - kh0) / sd;
+            c.off0x = (px + g->pad - kw0) / sd;
+            c.R = nj; c.S = ni;
+            if (nj == 0 || ni == 0) { c.R = 0; c.S = 1; }
+            c.wk0y = kh0; c.wk0x = kw0; c.wkstep = sd;
+            c.Qtot = c.R * c.S * c.SCc;
+            c.dst_step = sd; c.dst_oy = py; c.dst_ox = px;
+            c.M = (long long)g->N * c.DH * c.DW;
+            const int rc2 = dtype == CS_F32 ? dispatch_igemm<float>(c, colsum, nullptr, st) : dispatch_igemm<bf16_t>(c, colsum, nullptr, st);
+            if (rc2 != CS_OK) return rc2;
+        }
+    }
+    return CS_OK;
 }
 
 // =============================================================================================
@@ -704,20 +759,24 @@ struct WgradParams {
     long long M;
     int QE;           // R*S*C (elements)
     int SCc;          // C / chunk
-    long long m_per_split;   // multiple of 32
+    long long m_per_split;   // multiple of the K-step
 };
 
 template <typename T, int BM, int BN, bool TR>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     constexpr int CE = Elem<T>::kChunk;
-    constexpr int BKP = 32;                  // pixels per K-step
+    constexpr int BKP = 32;                         // pixels per K-step
+    // LDS row strides (elements).  bf16: +64 B per row so the 4 pixel rows of one transposing read fall on
+    // 4 disjoint 16-bank groups (256-B rows put them on the SAME banks: 60 % of LDS cycles were conflicts).
+    constexpr int LDA = sizeof(T) == 2 ? BM + 32 : BM;
+    constexpr int LDB = sizeof(T) == 2 ? BN + 32 : BN;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int ACPR = BM / CE;            // A chunks per pixel row
     constexpr int BCPR = BN / CE;
     constexpr int AI = BKP * ACPR / 256;     // chunks per thread
     constexpr int BI = BKP * BCPR / 256;
-    constexpr int ASTAGE = BKP * BM;         // elements
-    constexpr int BSTAGE = BKP * BN;
+    constexpr int ASTAGE = BKP * LDA;        // elements
+    constexpr int BSTAGE = BKP * LDB;
     static_assert(AI >= 1 && BI >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
@@ -809,10 +868,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         T* Bs = As + ASTAGE;
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<uint4*>(As + (ar + (256 / ACPR) * i) * BM + ac * CE) = ra[i];
+            *reinterpret_cast<uint4*>(As + (ar + (256 / ACPR) * i) * LDA + ac * CE) = ra[i];
 #pragma unroll
         for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<uint4*>(Bs + (br + (256 / BCPR) * i) * BN + bc * CE) = rb[i];
+            *reinterpret_cast<uint4*>(Bs + (br + (256 / BCPR) * i) * LDB + bc * CE) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -840,9 +899,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                 const int kr = 2 * s + hh;
                 float a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = reinterpret_cast<const float*>(As)[kr * BM + wm * (BM / 2) + i * 32 + l31];
+                for (int i = 0; i < TM; ++i) a[i] = reinterpret_cast<const float*>(As)[kr * LDA + wm * (BM / 2) + i * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = reinterpret_cast<const float*>(Bs)[kr * BN + wn * (BN / 2) + j * 32 + l31];
+                for (int j = 0; j < TN; ++j) b[j] = reinterpret_cast<const float*>(Bs)[kr * LDB + wn * (BN / 2) + j * 32 + l31];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -865,14 +924,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                         const int kr = 16 * s + 8 * hh + 4 * u + qq;
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
-                            const unsigned short* ap = reinterpret_cast<const unsigned short*>(As) + kr * BM +
+                            const unsigned short* ap = reinterpret_cast<const unsigned short*>(As) + kr * LDA +
                                                        wm * (BM / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
                             a[i].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                 (s16x4 __attribute__((address_space(3)))*)(ap));
                         }
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const unsigned short* bp = reinterpret_cast<const unsigned short*>(Bs) + kr * BN +
+                            const unsigned short* bp = reinterpret_cast<const unsigned short*>(Bs) + kr * LDB +
                                                        wn * (BN / 2) + j * 32 + 16 * (g16 & 1) + 4 * pp;
                             b[j].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                 (s16x4 __attribute__((address_space(3)))*)(bp));
@@ -884,10 +943,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                         const int kr = 16 * s + 8 * hh + e;
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
-                            a[i].h[e] = reinterpret_cast<const unsigned short*>(As)[kr * BM + wm * (BM / 2) + i * 32 + l31];
+                            a[i].h[e] = reinterpret_cast<const unsigned short*>(As)[kr * LDA + wm * (BM / 2) + i * 32 + l31];
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            b[j].h[e] = reinterpret_cast<const unsigned short*>(Bs)[kr * BN + wn * (BN / 2) + j * 32 + l31];
+                            b[j].h[e] = reinterpret_cast<const unsigned short*>(Bs)[kr * LDB + wn * (BN / 2) + j * 32 + l31];
                     }
                 }
 #pragma unroll
@@ -923,12 +982,25 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
     long long max_split = (p.M + 127) / 128;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
+    constexpr int BKP = 32;
+    constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
     long long per = (p.M + want - 1) / want;
-    per = ((per + 31) / 32) * 32;
+    per = ((per + BKP - 1) / BKP) * BKP;
     const int nsplit = (int)((p.M + per - 1) / per);
     p.m_per_split = per;
-    constexpr size_t lds = 2ull * 32 * (BM + BN) * sizeof(T);
+    constexpr size_t lds = 2ull * BKP * (BM + BN + 2 * PADE) * sizeof(T);
     dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), nsplit);
+    if (lds > 65536) {
+        static bool raised = false;      // per template instantiation
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BM, BN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                cs_set_error_("wgrad: cannot raise the dynamic LDS limit");
+                return CS_ERR_LAUNCH;
+            }
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
