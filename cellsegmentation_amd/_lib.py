@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcellseg_hip.so")
 
 CS_F32, CS_BF16 = 0, 1
-CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU = 0, 1, 2
+CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU, CS_ACT_SIGMOID = 0, 1, 2, 3
 
 
 class CsConvGeom(Structure):
@@ -41,9 +41,9 @@ _SIGNATURES = {
     "cs_colsum": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_maxpool3x3s2_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "cs_gap_avgmax_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P]),
-    "cs_gap_avgmax_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
-    "cs_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cs_gap_avgmax_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cs_gap_avgmax_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cs_linear_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cs_linear_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cs_softmax_ce": (c_int, [_P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "cs_softmax_prob1": (c_int, [_P, _P, c_int, c_int, _P]),
@@ -51,8 +51,14 @@ _SIGNATURES = {
     "cs_bn_stats": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_bn_finalize": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P, _P, c_int, _P]),
     "cs_bn_apply": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_longlong, c_int, _P]),
-    "cs_bn_bwd_reduce": (c_int, [_P, _P, c_int, _P, _P, c_longlong, c_int, _P, _P]),
-    "cs_bn_bwd_apply": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_longlong, c_int, _P, _P, _P, _P]),
+    "cs_bn_bwd_reduce": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_longlong, c_int, _P, _P]),
+    "cs_bn_bwd_apply": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_longlong, c_int, _P, _P, _P, _P]),
+    "cs_dwconv_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "cs_dwconv_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P]),
+    "cs_dwconv_wgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P]),
+    "cs_se_scale": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "cs_se_scale_bwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cs_rowscale_add": (c_int, [_P, c_int, _P, _P, _P, c_int, c_longlong, _P]),
     "cs_bilinear_ac_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_bilinear_ac_bwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_concat_channels": (c_int, [_P, _P, c_int, _P, c_longlong, c_int, c_int, _P]),

@@ -120,9 +120,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
     }
 }
 
+// gradient through the activation that follows the normalisation: ReLU is handled by the consumers' masks
+// (engine convention), SiLU needs u = gamma*xhat + beta: d silu(u)/du = sig*(1 + u*(1-sig)).
+__device__ __forceinline__ float act_grad(float g, float xh, float gm, float bt, int act) {
+    if (act != CS_ACT_SILU) return g;
+    const float u = gm * xh + bt;
+    const float sg = 1.f / (1.f + __expf(-u));
+    return g * sg * (1.f + u * (1.f - sg));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                             long long M, int C, double* __restrict__ sums,
                                                             int rows_per_block) {
     const int CG = C / 8;
@@ -139,15 +149,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
         if (live) {
-            float mu[8], rs[8];
+            float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { mu[e] = mean[cg * 8 + e]; rs[e] = rstd[cg * 8 + e]; }
+            for (int e = 0; e < 8; ++e) {
+                mu[e] = mean[cg * 8 + e]; rs[e] = rstd[cg * 8 + e];
+                gm[e] = gamma ? gamma[cg * 8 + e] : 1.f; bt[e] = beta ? beta[cg * 8 + e] : 0.f;
+            }
             for (long long r = r0 + rr; r < r1; r += rpar) {
                 float g[8], zz[8];
                 load8<T>(dy + r * C + cg * 8, g);
                 load8<T>(z + r * C + cg * 8, zz);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * (zz[e] - mu[e]) * rs[e]; }
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (zz[e] - mu[e]) * rs[e];
+                    const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
+                    s0[e] += gu; s1[e] += gu * xh;
+                }
             }
         }
         block_fold_atomic(s0, s1, width, rpar, cg, live, sums, sums + C);
@@ -157,7 +174,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                           const double* __restrict__ sums,
                                                            long long M, int C, T* __restrict__ dz, float* dgamma, float* dbeta) {
     const int CG = C / 8;
     const long long total = M * CG;
@@ -180,7 +198,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const int c = cg * 8 + e;
             const float xh = (zz[e] - mean[c]) * rstd[c];
             const float gm = gamma ? gamma[c] : 1.f;
-            o[e] = gm * rstd[c] * (g[e] - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
+            const float gu = act_grad(g[e], xh, gm, beta ? beta[c] : 0.f, act);
+            o[e] = gm * rstd[c] * (gu - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
         }
         store8<T>(dz + off, o);
     }
@@ -244,33 +263,33 @@ extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const fl
     return CS_OK;
 }
 
-extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd, long long M,
-                                int C, double* sums, void* stream) {
+extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, int act, long long M, int C, double* sums, void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rpb = rows_per_block_for(M);
     const int blocks = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
-                                     rstd, M, C, sums, rpb),
+                                     rstd, gamma, beta, act, M, C, sums, rpb),
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z,
-                                     mean, rstd, M, C, sums, rpb),
+                                     mean, rstd, gamma, beta, act, M, C, sums, rpb),
                   "bn_bwd_reduce");
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
 
 extern "C" int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
-                               const float* gamma, const double* sums, long long M, int C, void* dz, float* dgamma,
-                               float* dbeta, void* stream) {
+                               const float* gamma, const float* beta, int act, const double* sums, long long M, int C, void* dz,
+                               float* dgamma, float* dbeta, void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && dz && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int grid = grid_ew(M * (C / 8));
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
-                                     rstd, gamma, sums, M, C, (float*)dz, dgamma, dbeta),
+                                     rstd, gamma, beta, act, sums, M, C, (float*)dz, dgamma, dbeta),
                   hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, mean,
-                                     rstd, gamma, sums, M, C, (bf16_t*)dz, dgamma, dbeta),
+                                     rstd, gamma, beta, act, sums, M, C, (bf16_t*)dz, dgamma, dbeta),
                   "bn_bwd_apply");
     CS_LAUNCH_CHECK();
     return CS_OK;

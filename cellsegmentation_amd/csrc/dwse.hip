@@ -1,0 +1,336 @@
+// MBConv pieces of the EfficientNet path (model/efficientnet.py:81-122 on top of torchvision 0.11.2's
+// ConvNormActivation / SqueezeExcitation / StochasticDepth):
+//   depthwise k x k convolution (k in {3,5}, stride in {1,2}), forward / data-grad / weight-grad
+//   squeeze-excitation channel scaling and its backward
+//   per-sample (row mode) stochastic-depth scale + residual add
+// All HBM-bound NHWC kernels, 8 channels (one 16-byte access for bf16) per thread; k*k*2 FLOP per
+// 2-4 bytes, so nothing here belongs on MFMA.
+#include "cs_common.h"
+
+namespace {
+
+// y[n,oy,ox,c] = act( (sum_taps x[n,oy*s-p+kh,ox*s-p+kw,c] * w[kh][kw][c]) * scale[c] + shift[c] )
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int act, T* __restrict__ y, int N, int H, int W,
+                                                     int C, int R, int stride, int pad, int P, int Q) {
+    const int CG = C / 8;
+    const long long total = (long long)N * P * Q * CG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        long long t = idx / CG;
+        const int ox = (int)(t % Q); t /= Q;
+        const int oy = (int)(t % P);
+        const long long n = t / P;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int kh = 0; kh < R; ++kh) {
+            const int iy = oy * stride - pad + kh;
+            if (iy < 0 || iy >= H) continue;
+            for (int kw = 0; kw < R; ++kw) {
+                const int ix = ox * stride - pad + kw;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+                const float* wp = w + (kh * R + kw) * C + cg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e] * wp[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[e];
+            if (scale) v *= scale[cg * 8 + e];
+            if (shift) v += shift[cg * 8 + e];
+            if (act == CS_ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (act == CS_ACT_SILU) v = v / (1.f + __expf(-v));
+            acc[e] = v;
+        }
+        store8<T>(y + ((n * P + oy) * (long long)Q + ox) * C + cg * 8, acc);
+    }
+}
+
+// dx[n,iy,ix,c] = sum_taps dy[n,(iy+p-kh)/s,(ix+p-kw)/s,c] * w[kh][kw][c]   (gather form, no atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int N,
+                                                       int H, int W, int C, int R, int stride, int pad, int P, int Q) {
+    const int CG = C / 8;
+    const long long total = (long long)N * H * W * CG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        long long t = idx / CG;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long long n = t / H;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int kh = 0; kh < R; ++kh) {
+            const int ty = iy + pad - kh;
+            if (ty < 0 || ty % stride != 0) continue;
+            const int oy = ty / stride;
+            if (oy >= P) continue;
+            for (int kw = 0; kw < R; ++kw) {
+                const int tx = ix + pad - kw;
+                if (tx < 0 || tx % stride != 0) continue;
+                const int ox = tx / stride;
+                if (ox >= Q) continue;
+                float g[8];
+                load8<T>(dy + ((n * P + oy) * (long long)Q + ox) * C + cg * 8, g);
+                const float* wp = w + (kh * R + kw) * C + cg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += g[e] * wp[e];
+            }
+        }
+        store8<T>(dx + ((n * H + iy) * (long long)W + ix) * C + cg * 8, acc);
+    }
+}
+
+// dw[kh][kw][c] += sum over a slab of output pixels of dy * x.  Thread = (tap, channel group), workgroup = slab of
+// `pix_per_block` output pixels: each thread issues 8 atomics per slab (spread over R*R*C addresses).
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int N,
+                                                       int H, int W, int C, int R, int stride, int pad, int P, int Q, int pix_per_block) {
+    const int CG = C / 8;
+    const int work = R * R * CG;
+    const int item = blockIdx.y * blockDim.x + threadIdx.x;
+    if (item >= work) return;
+    const int cg = item % CG;
+    const int tap = item / CG;
+    const int kh = tap / R, kw = tap - kh * R;
+    const long long npix = (long long)N * P * Q;
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    long long p1 = p0 + pix_per_block;
+    if (p1 > npix) p1 = npix;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (long long pp = p0; pp < p1; ++pp) {
+        const long long n = pp / ((long long)P * Q);
+        const int rem = (int)(pp - n * (long long)P * Q);
+        const int oy = rem / Q, ox = rem - oy * Q;
+        const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        float g[8], v[8];
+        load8<T>(dy + pp * C + cg * 8, g);
+        load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dw + tap * C + cg * 8 + e, acc[e]);
+}
+
+// y[n,p,c] = x[n,p,c] * s[n,c]
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int N,
+                                                       int HW, int C) {
+    const int CG = C / 8;
+    const long long total = (long long)N * HW * CG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        const long long pix = idx / CG;
+        const long long n = pix / HW;
+        float v[8];
+        load8<T>(x + pix * C + cg * 8, v);
+        const float* sp = s + n * C + cg * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= sp[e];
+        store8<T>(y + pix * C + cg * 8, v);
+    }
+}
+
+// ds[n,c] = sum_p dy[n,p,c] * x[n,p,c]   (workgroup = (64 channel groups x 4 pixel lanes), one image)
+template <typename T>
+__global__ __launch_bounds__(256) void se_ds_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ ds, int HW, int C) {
+    const int CG = C / 8;
+    const int n = blockIdx.y;
+    const int cg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    __shared__ float red[4][64][8];
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (cg < CG) {
+        for (int p = part; p < HW; p += 4) {
+            float g[8], v[8];
+            const long long o = ((long long)n * HW + p) * C + cg * 8;
+            load8<T>(dy + o, g);
+            load8<T>(x + o, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[part][threadIdx.x & 63][e] = acc[e];
+    __syncthreads();
+    if (part == 0 && cg < CG) {
+        const int l = threadIdx.x & 63;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds[(long long)n * C + cg * 8 + e] = red[0][l][e] + red[1][l][e] + red[2][l][e] + red[3][l][e];
+    }
+}
+
+// dx[n,p,c] = dy[n,p,c] * s[n,c] + davg[n,c] / HW        (davg nullable)
+template <typename T>
+__global__ __launch_bounds__(256) void se_dx_kernel(const T* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ davg,
+                                                    T* __restrict__ dx, int N, int HW, int C) {
+    const int CG = C / 8;
+    const long long total = (long long)N * HW * CG;
+    const float inv = 1.f / (float)HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % CG);
+        const long long pix = idx / CG;
+        const long long n = pix / HW;
+        float g[8];
+        load8<T>(dy + pix * C + cg * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long o = n * C + cg * 8 + e;
+            g[e] = g[e] * s[o] + (davg ? davg[o] * inv : 0.f);
+        }
+        store8<T>(dx + pix * C + cg * 8, g);
+    }
+}
+
+// y[n,p,c] = a[n,p,c] * rs[n] + b[n,p,c]      (StochasticDepth "row" + residual add; rs nullable = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void rowscale_add_kernel(const T* __restrict__ a, const float* __restrict__ rs, const T* __restrict__ b,
+                                                           T* __restrict__ y, long long per_row, long long total8) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total8; idx += (long long)gridDim.x * blockDim.x) {
+        const long long o = idx * 8;
+        const float s = rs ? rs[o / per_row] : 1.f;
+        float va[8], vb[8];
+        load8<T>(a + o, va);
+        if (b) {
+            load8<T>(b + o, vb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) va[e] = va[e] * s + vb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) va[e] *= s;
+        }
+        store8<T>(y + o, va);
+    }
+}
+
+inline int grid_ew(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define CS_T_SWITCH(dtype, NAME, F32, BF16)                                            \
+    if (dtype == CS_F32) { F32; } else if (dtype == CS_BF16) { BF16; }                 \
+    else { cs_set_error_(NAME ": bad dtype"); return CS_ERR_INVALID_ARG; }
+
+static int check_dw(const CsConvGeom* g, const char* what) {
+    if (!g || g->R != g->S || g->R < 1 || g->C % 8 != 0 || g->K != g->C || g->stride < 1 ||
+        g->P != (g->H + 2 * g->pad - g->R) / g->stride + 1 || g->Q != (g->W + 2 * g->pad - g->S) / g->stride + 1) {
+        cs_set_error_(what);
+        return CS_ERR_INVALID_ARG;
+    }
+    return CS_OK;
+}
+
+extern "C" int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, const float* scale, const float* shift,
+                             int act, void* y, void* stream) {
+    int rc = check_dw(g, "dwconv_fwd: bad geometry (square filter, K == C, C % 8 == 0 required)");
+    if (rc) return rc;
+    CS_CHECK_ARG(x && w_hwc && y, "dwconv_fwd: NULL tensor");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_ew((long long)g->N * g->P * g->Q * (g->C / 8));
+    CS_T_SWITCH(dtype, "dwconv_fwd",
+                hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, w_hwc, scale, shift, act, (float*)y,
+                                   g->N, g->H, g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q),
+                hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w_hwc, scale, shift, act,
+                                   (bf16_t*)y, g->N, g->H, g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, const float* w_hwc, void* dx, void* stream) {
+    int rc = check_dw(g, "dwconv_dgrad: bad geometry");
+    if (rc) return rc;
+    CS_CHECK_ARG(dy && w_hwc && dx, "dwconv_dgrad: NULL tensor");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_ew((long long)g->N * g->H * g->W * (g->C / 8));
+    CS_T_SWITCH(dtype, "dwconv_dgrad",
+                hipLaunchKernelGGL(dw_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, w_hwc, (float*)dx, g->N, g->H,
+                                   g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q),
+                hipLaunchKernelGGL(dw_dgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, w_hwc, (bf16_t*)dx, g->N, g->H,
+                                   g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, void* stream) {
+    int rc = check_dw(g, "dwconv_wgrad: bad geometry");
+    if (rc) return rc;
+    CS_CHECK_ARG(x && dy && dw_hwc, "dwconv_wgrad: NULL tensor");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long npix = (long long)g->N * g->P * g->Q;
+    long long ppb = (npix + 1023) / 1024;
+    if (ppb < 64) ppb = 64;
+    const int work = g->R * g->R * (g->C / 8);
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)((work + 255) / 256));
+    CS_T_SWITCH(dtype, "dwconv_wgrad",
+                hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, dw_hwc, g->N, g->H, g->W,
+                                   g->C, g->R, g->stride, g->pad, g->P, g->Q, (int)ppb),
+                hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw_hwc, g->N, g->H,
+                                   g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q, (int)ppb));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_se_scale(const void* x, int dtype, const float* s, void* y, int N, int HW, int C, void* stream) {
+    CS_CHECK_ARG(x && s && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_ew((long long)N * HW * (C / 8));
+    CS_T_SWITCH(dtype, "se_scale",
+                hipLaunchKernelGGL(se_scale_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, s, (float*)y, N, HW, C),
+                hipLaunchKernelGGL(se_scale_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, s, (bf16_t*)y, N, HW, C));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_se_scale_bwd(const void* dy, const void* x, int dtype, const float* s, const float* davg, float* ds, void* dx, int N,
+                               int HW, int C, int phase, void* stream) {
+    /* phase 0: ds[n,c] = sum_p dy*x ; phase 1: dx = dy*s + davg/HW */
+    CS_CHECK_ARG(dy && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_bwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (phase == 0) {
+        CS_CHECK_ARG(x && ds, "se_scale_bwd: phase 0 needs x and ds");
+        dim3 grid((C / 8 + 63) / 64, N);
+        CS_T_SWITCH(dtype, "se_scale_bwd",
+                    hipLaunchKernelGGL(se_ds_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, ds, HW, C),
+                    hipLaunchKernelGGL(se_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, ds, HW, C));
+    } else {
+        CS_CHECK_ARG(s && dx, "se_scale_bwd: phase 1 needs s and dx");
+        const int grid = grid_ew((long long)N * HW * (C / 8));
+        CS_T_SWITCH(dtype, "se_scale_bwd",
+                    hipLaunchKernelGGL(se_dx_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, s, davg, (float*)dx, N, HW, C),
+                    hipLaunchKernelGGL(se_dx_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, s, davg, (bf16_t*)dx, N, HW, C));
+    }
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_rowscale_add(const void* a, int dtype, const float* row_scale, const void* b, void* y, int N, long long per_row,
+                               void* stream) {
+    CS_CHECK_ARG(a && y && N > 0 && per_row > 0 && per_row % 8 == 0, "rowscale_add: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total8 = (long long)N * per_row / 8;
+    const int grid = grid_ew(total8);
+    CS_T_SWITCH(dtype, "rowscale_add",
+                hipLaunchKernelGGL(rowscale_add_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a, row_scale, (const float*)b,
+                                   (float*)y, per_row, total8),
+                hipLaunchKernelGGL(rowscale_add_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)a, row_scale, (const bf16_t*)b,
+                                   (bf16_t*)y, per_row, total8));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}

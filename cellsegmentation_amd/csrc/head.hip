@@ -8,8 +8,8 @@ namespace {
 
 // one wave per output element y[m][n]
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ b, float* __restrict__ y, int M, int N,
-                                                         int K, int act) {
+                                                         const float* __restrict__ b, float* __restrict__ y, float* __restrict__ pre,
+                                                         int M, int N, int K, int act) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= (long long)M * N) return;
@@ -21,9 +21,24 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     acc = wave_sum(acc);
     if (lane == 0) {
         float v = acc + (b ? b[n] : 0.f);
+        if (pre) pre[(long long)m * N + n] = v;
         if (act == CS_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == CS_ACT_SILU) v = v / (1.f + expf(-v));
+        else if (act == CS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
         y[(long long)m * N + n] = v;
     }
+}
+
+// upstream gradient through the output activation; `y` is the stored OUTPUT for ReLU / sigmoid and the stored
+// PRE-activation for SiLU
+__device__ __forceinline__ float lin_act_grad(float g, float yv, int act) {
+    if (act == CS_ACT_RELU) return yv > 0.f ? g : 0.f;
+    if (act == CS_ACT_SIGMOID) return g * yv * (1.f - yv);
+    if (act == CS_ACT_SILU) {
+        const float sg = 1.f / (1.f + expf(-yv));
+        return g * sg * (1.f + yv * (1.f - sg));
+    }
+    return g;
 }
 
 // dx[m][k] = sum_n g[m][n] w[n][k]
@@ -35,8 +50,7 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
     const int m = (int)(idx / K), k = (int)(idx % K);
     float acc = 0.f;
     for (int n = 0; n < N; ++n) {
-        float g = dy[(long long)m * N + n];
-        if (act == CS_ACT_RELU && !(y[(long long)m * N + n] > 0.f)) g = 0.f;
+        const float g = lin_act_grad(dy[(long long)m * N + n], act ? y[(long long)m * N + n] : 0.f, act);
         acc += g * w[(long long)n * K + k];
     }
     dx[idx] = acc;
@@ -52,8 +66,7 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     const int n = (int)(idx / K), k = (int)(idx % K);
     float acc = 0.f, accb = 0.f;
     for (int m = 0; m < M; ++m) {
-        float g = dy[(long long)m * N + n];
-        if (act == CS_ACT_RELU && !(y[(long long)m * N + n] > 0.f)) g = 0.f;
+        const float g = lin_act_grad(dy[(long long)m * N + n], act ? y[(long long)m * N + n] : 0.f, act);
         acc += g * x[(long long)m * K + k];
         accb += g;
     }
@@ -200,12 +213,12 @@ __global__ __launch_bounds__(256) void softmax_ch_bwd_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act,
+extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, float* preact, int M, int N, int K, int act,
                              void* stream) {
     CS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long waves = (long long)M * N;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, w, b, y, M, N, K, act);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, w, b, y, preact, M, N, K, act);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
@@ -213,7 +226,7 @@ extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, flo
 extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
                              float* db, int M, int N, int K, int accumulate, void* stream) {
     CS_CHECK_ARG(dy && M > 0 && N > 0 && K > 0, "linear_bwd: bad arguments");
-    CS_CHECK_ARG(act != CS_ACT_RELU || y, "linear_bwd: relu needs y");
+    CS_CHECK_ARG(act == CS_ACT_NONE || y, "linear_bwd: an output activation needs y (SiLU: the pre-activation)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dx) {
         CS_CHECK_ARG(w, "linear_bwd: dx needs w");

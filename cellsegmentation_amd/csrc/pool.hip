@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // Global avg+max: workgroup = 64 channel-groups x 4 row partitions.
 template <typename T>
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ feat,
-                                                      int32_t* __restrict__ amax, int HW, int C) {
+                                                      int32_t* __restrict__ amax, int HW, int C, int with_max) {
     const int CG = C / 8;
     const int n = blockIdx.y;
     const int cg = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, f
                 // first (smallest index) maximum wins ties, matching a sequential strict-> scan
                 if (bi == 0x7fffffff || mq > m || (mq == m && iq < bi)) { m = mq; bi = iq; }
             }
-            feat[(long long)n * C + cg * 8 + e] = s / (float)HW + m;
+            feat[(long long)n * C + cg * 8 + e] = s / (float)HW + (with_max ? m : 0.f);
             if (amax) amax[(long long)n * C + cg * 8 + e] = bi;
         }
     }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, f
 template <typename T>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dfeat, const int32_t* __restrict__ amax,
                                                       const T* __restrict__ x, T* __restrict__ dx, int N, int HW, int C,
-                                                      int relu_mask) {
+                                                      int relu_mask, int with_max) {
     const int CG = C / 8;
     const long long total = (long long)N * HW * CG;
     const float inv = 1.f / (float)HW;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float g = dfeat[n * C + cg * 8 + e];
-            v[e] = g * inv + (amax[n * C + cg * 8 + e] == p ? g : 0.f);
+            v[e] = g * inv + ((with_max && amax[n * C + cg * 8 + e] == p) ? g : 0.f);
         }
         const long long o = (n * HW + p) * C + cg * 8;
         if (relu_mask) {
@@ -231,15 +231,16 @@ extern "C" int cs_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, const 
     return CS_OK;
 }
 
-extern "C" int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, int N, int HW, int C, void* stream) {
+extern "C" int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, int N, int HW, int C, int with_max,
+                                 void* stream) {
     CS_CHECK_ARG(x && feat, "gap_fwd: NULL tensor");
     CS_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad extents");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((C / 8 + 63) / 64, N);
     if (dtype == CS_F32)
-        hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, feat, argmax, HW, C);
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, feat, argmax, HW, C, with_max);
     else if (dtype == CS_BF16)
-        hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, feat, argmax, HW, C);
+        hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, feat, argmax, HW, C, with_max);
     else
         CS_CHECK_ARG(false, "gap_fwd: bad dtype");
     CS_LAUNCH_CHECK();
@@ -247,16 +248,16 @@ extern "C" int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t*
 }
 
 extern "C" int cs_gap_avgmax_bwd(const float* dfeat, const int32_t* argmax, const void* x, int dtype, void* dx, int N, int HW,
-                                 int C, int relu_mask, void* stream) {
-    CS_CHECK_ARG(dfeat && argmax && dx, "gap_bwd: NULL tensor");
+                                 int C, int relu_mask, int with_max, void* stream) {
+    CS_CHECK_ARG(dfeat && dx && (argmax || !with_max), "gap_bwd: NULL tensor");
     CS_CHECK_ARG(!relu_mask || x, "gap_bwd: relu_mask needs x");
     CS_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_bwd: bad extents");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long total = (long long)N * HW * (C / 8);
     if (dtype == CS_F32)
-        hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, argmax, (const float*)x, (float*)dx, N, HW, C, relu_mask);
+        hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, argmax, (const float*)x, (float*)dx, N, HW, C, relu_mask, with_max);
     else if (dtype == CS_BF16)
-        hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, argmax, (const bf16_t*)x, (bf16_t*)dx, N, HW, C, relu_mask);
+        hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, argmax, (const bf16_t*)x, (bf16_t*)dx, N, HW, C, relu_mask, with_max);
     else
         CS_CHECK_ARG(false, "gap_bwd: bad dtype");
     CS_LAUNCH_CHECK();

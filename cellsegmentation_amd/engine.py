@@ -26,7 +26,7 @@ import torch
 
 from . import kernels as K
 
-ACT_NONE, ACT_RELU = K.CS_ACT_NONE, K.CS_ACT_RELU
+ACT_NONE, ACT_RELU, ACT_SILU = K.CS_ACT_NONE, K.CS_ACT_RELU, K.CS_ACT_SILU
 
 
 class ConvUnit:
@@ -49,6 +49,50 @@ class ConvUnit:
 
     def inputs(self):
         return [self.src] + ([self.res] if self.res is not None else [])
+
+
+class DwConvUnit:
+    """Depthwise k x k Conv2d(groups=C, bias=False) + BatchNorm2d + activation (MBConv, efficientnet.py:101-103)."""
+    kind = "dw"
+
+    def __init__(self, name, conv, bn, act, src, dst):
+        self.name, self.conv, self.bn, self.act, self.src, self.dst = name, conv, bn, act, src, dst
+        if conv.groups != conv.in_channels or conv.in_channels != conv.out_channels or conv.bias is not None:
+            raise ValueError(f"{name}: not a bias-free depthwise convolution")
+
+    def params(self):
+        return [("weight", self.conv.weight), ("gamma", self.bn.weight), ("beta", self.bn.bias)]
+
+    def inputs(self):
+        return [self.src]
+
+
+class SEUnit:
+    """torchvision SqueezeExcitation: x * sigmoid(fc2(silu(fc1(avgpool(x)))))  (efficientnet.py:105-107)."""
+    kind = "se"
+
+    def __init__(self, name, fc1, fc2, src, dst):
+        self.name, self.fc1, self.fc2, self.src, self.dst = name, fc1, fc2, src, dst
+
+    def params(self):
+        return [("w1", self.fc1.weight), ("b1", self.fc1.bias), ("w2", self.fc2.weight), ("b2", self.fc2.bias)]
+
+    def inputs(self):
+        return [self.src]
+
+
+class RowScaleAddUnit:
+    """StochasticDepth(p, "row") on `a`, then + `b` (efficientnet.py:116-121); only planned when training with p > 0."""
+    kind = "sd"
+
+    def __init__(self, a, b, dst, p):
+        self.a, self.b, self.dst, self.p = a, b, dst, p
+
+    def params(self):
+        return []
+
+    def inputs(self):
+        return [self.a, self.b]
 
 
 class PoolUnit:
@@ -192,6 +236,45 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 y = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), res, u.act)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=True, z=z if save else None, mean=mean, rstd=rstd)
             t[u.dst] = y
+        elif u.kind == "dw":
+            x = t[u.src]
+            N, H, W, C = x.shape
+            conv, bn = u.conv, u.bn
+            R = conv.kernel_size[0]
+            geom = K.make_geom(N, H, W, C, C, R, R, conv.stride[0], conv.padding[0])
+            w_hwc = conv.weight.detach()[:, 0].permute(1, 2, 0).contiguous()
+            if _bn_uses_batch_stats(bn, bn_train):
+                z = K.dwconv_fwd(geom, x, w_hwc)
+                M = N * geom.P * geom.Q
+                momentum = bn.momentum if bn.momentum is not None else 0.1
+                mean, rstd = K.bn_finalize(K.bn_stats(z), M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
+                                           bn.running_var if bn.track_running_stats else None)
+                if bn.track_running_stats and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+                t[u.dst] = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), None, u.act)
+                aux[ui] = SimpleNamespace(geom=geom, train=True, z=z if save else None, mean=mean, rstd=rstd, w_hwc=w_hwc)
+            else:
+                scale, shift, _ = K.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+                t[u.dst] = K.dwconv_fwd(geom, x, w_hwc, scale, shift, u.act)
+                aux[ui] = SimpleNamespace(geom=geom, train=False)
+        elif u.kind == "se":
+            x = t[u.src]
+            C = x.shape[-1]
+            w1 = u.fc1.weight.detach().view(u.fc1.out_channels, C)
+            w2 = u.fc2.weight.detach().view(C, u.fc2.in_channels)
+            avg, _ = K.gap_fwd(x, with_max=False)
+            h1, u1 = K.linear_fwd(avg, w1, u.fc1.bias.detach(), K.CS_ACT_SILU, want_preact=True)
+            sc = K.linear_fwd(h1, w2, u.fc2.bias.detach(), K.CS_ACT_SIGMOID)
+            t[u.dst] = K.se_scale(x, sc)
+            aux[ui] = SimpleNamespace(avg=avg, h1=h1, u1=u1, s=sc, w1=w1, w2=w2)
+        elif u.kind == "sd":
+            a = t[u.a]
+            keep = 1.0 - u.p
+            noise = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device).bernoulli_(keep)
+            if keep > 0:
+                noise.div_(keep)
+            t[u.dst] = K.rowscale_add(a, noise, t[u.b])
+            aux[ui] = SimpleNamespace(noise=noise)
         elif u.kind == "pool":
             y, am = K.maxpool_fwd(t[u.src], want_argmax=save)
             aux[ui] = SimpleNamespace(argmax=am, in_hw=tuple(t[u.src].shape[1:3]))
@@ -266,9 +349,13 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             want_b = need(ui, "bias")
             want_bn = need(ui, "gamma") or need(ui, "beta")
             dz = g
+            if u.act == ACT_SILU and not a.train:
+                raise NotImplementedError(f"{u.name}: backward through a folded (eval-mode) BN + SiLU is not supported; "
+                                          "EfficientNet trains with batch statistics (efficientnet.py:308-312)")
             if a.train:
                 bn = u.bn
-                dz, dgamma, dbeta = K.bn_bwd(g, a.z, a.mean, a.rstd, bn.weight.detach(), want_param_grads=want_bn)
+                dz, dgamma, dbeta = K.bn_bwd(g, a.z, a.mean, a.rstd, bn.weight.detach(), want_param_grads=want_bn,
+                                             beta=bn.bias.detach(), act=ACT_SILU if u.act == ACT_SILU else ACT_NONE)
                 if need(ui, "gamma"):
                     pgrads[pindex[(ui, "gamma")]] = dgamma[:Kc]
                 if need(ui, "beta"):
@@ -312,6 +399,49 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 grads[u.src] = dx
                 if final:
                     gsum_cache[u.src] = cs
+        elif u.kind == "dw":
+            if not a.train:
+                raise NotImplementedError(f"{u.name}: backward through an eval-mode depthwise block is not supported")
+            bn, x = u.bn, t[u.src]
+            want_bn = need(ui, "gamma") or need(ui, "beta")
+            dz, dgamma, dbeta = K.bn_bwd(g, a.z, a.mean, a.rstd, bn.weight.detach(), want_param_grads=want_bn, beta=bn.bias.detach(),
+                                         act=ACT_SILU if u.act == ACT_SILU else ACT_NONE)
+            if need(ui, "gamma"):
+                pgrads[pindex[(ui, "gamma")]] = dgamma
+            if need(ui, "beta"):
+                pgrads[pindex[(ui, "beta")]] = dbeta
+            if need(ui, "weight"):
+                pgrads[pindex[(ui, "weight")]] = K.dwconv_wgrad(a.geom, x, dz).permute(2, 0, 1).unsqueeze(1).contiguous()
+            if requires.get(u.src, False):
+                left[u.src] -= 1
+                dx = K.dwconv_dgrad(a.geom, dz, a.w_hwc)
+                pending = grads.pop(u.src, None)
+                grads[u.src] = dx if pending is None else K.rowscale_add(dx, None, pending)
+        elif u.kind == "se":
+            x = t[u.src]
+            ds = K.se_scale_bwd_ds(g, x)
+            want2 = need(ui, "w2") or need(ui, "b2")
+            want1 = need(ui, "w1") or need(ui, "b1")
+            dh1, dw2, db2 = K.linear_bwd(a.h1, a.w2, ds, a.s, K.CS_ACT_SIGMOID, True, want2, want2)
+            davg, dw1, db1 = K.linear_bwd(a.avg, a.w1, dh1, a.u1, K.CS_ACT_SILU, True, want1, want1)
+            if need(ui, "w2"):
+                pgrads[pindex[(ui, "w2")]] = dw2.view_as(u.fc2.weight)
+            if need(ui, "b2"):
+                pgrads[pindex[(ui, "b2")]] = db2
+            if need(ui, "w1"):
+                pgrads[pindex[(ui, "w1")]] = dw1.view_as(u.fc1.weight)
+            if need(ui, "b1"):
+                pgrads[pindex[(ui, "b1")]] = db1
+            if requires.get(u.src, False):
+                left[u.src] -= 1
+                if u.src in grads:
+                    raise NotImplementedError("engine: SE input with several consumers")
+                grads[u.src] = K.se_scale_bwd_dx(g, a.s, davg)
+        elif u.kind == "sd":
+            if requires.get(u.b, False):
+                contribute(u.b, g, masked=True)
+            if requires.get(u.a, False):
+                contribute(u.a, K.rowscale_add(g, a.noise, None), masked=True)
         elif u.kind == "pool":
             if requires.get(u.src, False):
                 left[u.src] -= 1

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU, CS_BF16, CS_F32, CsConvGeom  # noqa: F401
+from ._lib import CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SIGMOID, CS_ACT_SILU, CS_BF16, CS_F32, CsConvGeom  # noqa: F401
 
 
 def _code(dtype):
@@ -215,16 +215,16 @@ def bn_apply(z, mean, rstd, gamma, beta, residual=None, act=CS_ACT_NONE, out=Non
     return y
 
 
-def bn_bwd(dy, z, mean, rstd, gamma, want_param_grads=True):
-    """returns dz, dgamma, dbeta"""
+def bn_bwd(dy, z, mean, rstd, gamma, want_param_grads=True, beta=None, act=CS_ACT_NONE):
+    """returns dz, dgamma, dbeta.  act=CS_ACT_SILU differentiates through the SiLU that follows the BN."""
     C = z.shape[-1]
     M = z.numel() // C
     sums = new_stats(C, z.device)
     lib = _lib.load()
-    _lib.check(lib.cs_bn_bwd_reduce(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), M, C, _p(sums), _stream()), "bn_bwd_reduce")
+    _lib.check(lib.cs_bn_bwd_reduce(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(beta), act, M, C, _p(sums), _stream()), "bn_bwd_reduce")
     dz = torch.empty_like(z)
     dg = torch.empty((2, C), dtype=torch.float32, device=z.device) if want_param_grads else None
-    _lib.check(lib.cs_bn_bwd_apply(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(sums), M, C, _p(dz),
+    _lib.check(lib.cs_bn_bwd_apply(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _p(sums), M, C, _p(dz),
                                    _p(dg[0]) if dg is not None else None, _p(dg[1]) if dg is not None else None, _stream()),
                "bn_bwd_apply")
     return dz, (dg[0] if dg is not None else None), (dg[1] if dg is not None else None)
@@ -265,6 +265,56 @@ def split(whole, Ca, want_a=True, want_b=True):
     return a, b
 
 
+# ---------------------------------------------------------------- MBConv pieces
+def dwconv_fwd(geom, x, w_hwc, scale=None, shift=None, act=CS_ACT_NONE):
+    y = torch.empty((geom.N, geom.P, geom.Q, geom.C), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().cs_dwconv_fwd(ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_hwc), _p(scale), _p(shift), act, _p(y), _stream()),
+               "dwconv_fwd")
+    return y
+
+
+def dwconv_dgrad(geom, dy, w_hwc):
+    dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().cs_dwconv_dgrad(ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_hwc), _p(dx), _stream()), "dwconv_dgrad")
+    return dx
+
+
+def dwconv_wgrad(geom, x, dy):
+    dw = torch.zeros((geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cs_dwconv_wgrad(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw), _stream()), "dwconv_wgrad")
+    return dw
+
+
+def se_scale(x, s):
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().cs_se_scale(_p(x), _code(x.dtype), _p(s), _p(y), N, H * W, C, _stream()), "se_scale")
+    return y
+
+
+def se_scale_bwd_ds(dy, x):
+    N, H, W, C = x.shape
+    ds = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cs_se_scale_bwd(_p(dy), _p(x), _code(x.dtype), None, None, _p(ds), None, N, H * W, C, 0, _stream()),
+               "se_scale_bwd(ds)")
+    return ds
+
+
+def se_scale_bwd_dx(dy, s, davg):
+    N, H, W, C = dy.shape
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.load().cs_se_scale_bwd(_p(dy), None, _code(dy.dtype), _p(s), _p(davg), None, _p(dx), N, H * W, C, 1, _stream()),
+               "se_scale_bwd(dx)")
+    return dx
+
+
+def rowscale_add(a, row_scale, b):
+    N = a.shape[0]
+    y = torch.empty_like(a)
+    _lib.check(_lib.load().cs_rowscale_add(_p(a), _code(a.dtype), _p(row_scale), _p(b), _p(y), N, a.numel() // N, _stream()), "rowscale_add")
+    return y
+
+
 # ---------------------------------------------------------------- pooling
 def maxpool_fwd(x, want_argmax=True):
     N, H, W, C = x.shape
@@ -284,29 +334,31 @@ def maxpool_bwd(dy, argmax, y_mask, in_hw):
     return dx
 
 
-def gap_fwd(x):
+def gap_fwd(x, with_max=True):
     N, H, W, C = x.shape
     feat = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    am = torch.empty((N, C), dtype=torch.int32, device=x.device)
-    _lib.check(_lib.load().cs_gap_avgmax_fwd(_p(x), _code(x.dtype), _p(feat), _p(am), N, H * W, C, _stream()), "gap_fwd")
+    am = torch.empty((N, C), dtype=torch.int32, device=x.device) if with_max else None
+    _lib.check(_lib.load().cs_gap_avgmax_fwd(_p(x), _code(x.dtype), _p(feat), _p(am), N, H * W, C, 1 if with_max else 0, _stream()),
+               "gap_fwd")
     return feat, am
 
 
-def gap_bwd(dfeat, argmax, x, relu_mask):
+def gap_bwd(dfeat, argmax, x, relu_mask, with_max=True):
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
     _lib.check(_lib.load().cs_gap_avgmax_bwd(_p(dfeat), _p(argmax), _p(x), _code(x.dtype), _p(dx), N, H * W, C,
-                                             1 if relu_mask else 0, _stream()), "gap_bwd")
+                                             1 if relu_mask else 0, 1 if with_max else 0, _stream()), "gap_bwd")
     return dx
 
 
 # ---------------------------------------------------------------- heads / losses
-def linear_fwd(x, w, b, act=CS_ACT_NONE):
+def linear_fwd(x, w, b, act=CS_ACT_NONE, want_preact=False):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().cs_linear_fwd(_p(x), _p(w), _p(b), _p(y), M, N, K, act, _stream()), "linear_fwd")
-    return y
+    pre = torch.empty_like(y) if want_preact else None
+    _lib.check(_lib.load().cs_linear_fwd(_p(x), _p(w), _p(b), _p(y), _p(pre), M, N, K, act, _stream()), "linear_fwd")
+    return (y, pre) if want_preact else y
 
 
 def linear_bwd(x, w, dy, y=None, act=CS_ACT_NONE, need_dx=True, need_dw=True, need_db=True):

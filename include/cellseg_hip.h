@@ -28,7 +28,7 @@ extern "C" {
 
 enum { CS_F32 = 0, CS_BF16 = 1 };
 enum { CS_OK = 0, CS_ERR_INVALID_ARG = -1, CS_ERR_LAUNCH = -2, CS_ERR_UNSUPPORTED = -3 };
-enum { CS_ACT_NONE = 0, CS_ACT_RELU = 1, CS_ACT_SILU = 2 };
+enum { CS_ACT_NONE = 0, CS_ACT_RELU = 1, CS_ACT_SILU = 2, CS_ACT_SIGMOID = 3 };
 
 int cs_abi_version(void);
 const char* cs_last_error(void);
@@ -69,13 +69,15 @@ int cs_bn_finalize(const double* stats, long long M, float eps, float momentum, 
 /* y = act( gamma*(z-mean)*rstd + beta + residual ); gamma/beta/residual nullable. */
 int cs_bn_apply(const void* z, int dtype, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream);
-/* sums fp64 [2][C] (zeroed by caller): sum dy, sum dy*xhat with xhat=(z-mean)*rstd. */
-int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd, long long M,
-                     int C, double* sums, void* stream);
-/* dz = gamma*rstd*( dy - sums0/M - xhat*sums1/M ); dgamma=sums1, dbeta=sums0 (fp32, nullable). */
+/* sums fp64 [2][C] (zeroed by caller): sum g, sum g*xhat with xhat=(z-mean)*rstd and g = dy, or for
+ * act==CS_ACT_SILU g = dy*silu'(gamma*xhat+beta) (the activation that follows the BN; ReLU gradients are
+ * already masked by the consumers, see engine.py). gamma/beta nullable (1/0). */
+int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int act, long long M, int C, double* sums, void* stream);
+/* dz = gamma*rstd*( g - sums0/M - xhat*sums1/M ); dgamma=sums1, dbeta=sums0 (fp32, nullable). */
 int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
-                    const float* gamma, const double* sums, long long M, int C, void* dz, float* dgamma,
-                    float* dbeta, void* stream);
+                    const float* gamma, const float* beta, int act, const double* sums, long long M, int C, void* dz,
+                    float* dgamma, float* dbeta, void* stream);
 
 /* ---- weight staging -------------------------------------------------------------------------
  * w[K][Cin][R][S] fp32 (torch Conv2d.weight) times optional per-K `scale` ->
@@ -133,11 +135,13 @@ int cs_maxpool3x3s2_fwd(const void* x, int dtype, void* y, uint8_t* argmax, int 
 int cs_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, const void* y_mask, int dtype, void* dx, int N, int H,
                         int W, int C, int P, int Q, void* stream);
 /* AdaptiveAvgPool2d(1)+AdaptiveMaxPool2d(1) summed (resnet.py:266,274): feat[N][C] fp32,
- * argmax[N][C] int32 = first spatial index of the maximum. */
-int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, int N, int HW, int C, void* stream);
+ * argmax[N][C] int32 = first spatial index of the maximum.  with_max==0: average only (the squeeze of
+ * torchvision's SqueezeExcitation, efficientnet.py:107). */
+int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t* argmax, int N, int HW, int C, int with_max,
+                      void* stream);
 /* dx[n][p][c] = ( dfeat[n][c]/HW + (p==argmax[n][c]) * dfeat[n][c] ) * [x>0 if relu_mask]. */
 int cs_gap_avgmax_bwd(const float* dfeat, const int32_t* argmax, const void* x, int dtype, void* dx, int N, int HW,
-                      int C, int relu_mask, void* stream);
+                      int C, int relu_mask, int with_max, void* stream);
 
 /* ---- segmentation decoder data movement ------------------------------------------------------
  * F.interpolate(mode="bilinear", align_corners=True) (resnet.py:282,287,292,297,300): x[N][H][W][C] -> y[N][P][Q][C] */
@@ -149,11 +153,30 @@ int cs_bilinear_ac_bwd(const void* dy, const void* mask, int dtype, void* dx, in
 int cs_concat_channels(const void* a, const void* b, int dtype, void* out, long long M, int Ca, int Cb, void* stream);
 int cs_split_channels(const void* whole, int dtype, void* a, void* b, long long M, int Ca, int Cb, void* stream);
 
+/* ---- MBConv pieces (model/efficientnet.py:81-122; torchvision 0.11.2 ConvNormActivation with groups=C,
+ * SqueezeExcitation, StochasticDepth("row")) -------------------------------------------------------
+ * depthwise conv: geometry with K == C, R == S; w_hwc fp32 [R][S][C]; optional fused per-channel
+ * scale/shift (eval BN) and activation. */
+int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, const float* scale, const float* shift,
+                  int act, void* y, void* stream);
+int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, const float* w_hwc, void* dx, void* stream);
+/* dw_hwc[R][S][C] fp32 += ... (zeroed by the caller) */
+int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, void* stream);
+/* y[n][p][c] = x[n][p][c]*s[n][c] */
+int cs_se_scale(const void* x, int dtype, const float* s, void* y, int N, int HW, int C, void* stream);
+/* phase 0: ds[n][c] = sum_p dy*x ; phase 1: dx = dy*s + davg[n][c]/HW (davg nullable) */
+int cs_se_scale_bwd(const void* dy, const void* x, int dtype, const float* s, const float* davg, float* ds, void* dx, int N,
+                    int HW, int C, int phase, void* stream);
+/* y = a*row_scale[n] + b over N rows of per_row elements (row_scale, b nullable) */
+int cs_rowscale_add(const void* a, int dtype, const float* row_scale, const void* b, void* y, int N, long long per_row,
+                    void* stream);
+
 /* ---- heads: Linear (resnet.py:126,137,140,150), losses (train/train.py:34,80-83) ------------- */
-/* y[M][N] = x[M][K] @ w[N][K]^T + b[N]  (fp32; b nullable; act applied last) */
-int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act, void* stream);
-/* dx[M][K] = dy @ w (nullable dx); dw[N][K] (+)= dy^T @ x; db[N] (+)= colsum(dy).  dy is first
- * multiplied by [y>0] when act==CS_ACT_RELU (y required then). */
+/* y[M][N] = act( x[M][K] @ w[N][K]^T + b[N] )  (fp32; b nullable; preact nullable: the value before act) */
+int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, float* preact, int M, int N, int K, int act,
+                  void* stream);
+/* dx[M][K] = g @ w (nullable dx); dw[N][K] (+)= g^T @ x; db[N] (+)= colsum(g), g = dy through the output
+ * activation: `y` = stored output for ReLU / sigmoid, stored PRE-activation for SiLU. */
 int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
                   float* db, int M, int N, int K, int accumulate, void* stream);
 /* CrossEntropyLoss(mean) * gamma on logits[M][C]; loss: 1 fp32 (overwritten); dlogits nullable. */

@@ -298,3 +298,63 @@ def get_tiles_coords(h, w, interval, size):
     """dataset/dataset.py:718-742: upper-left (row, col) of every tile, row-major, with a final
     border-aligned row/column when the stride does not land on the edge."""
     return [(x, y) for x in _axis_origins(h, interval, size) for y in _axis_origins(w, interval, size)]
+
+
+# ---------------------------------------------------------------------------------------------
+# EfficientNet branch -- PARITY UNPINNED by the reference (torchvision==0.11.2 is neither vendored in
+# /root/reference nor installed): restates model/efficientnet.py:81-122,179-214,295-333 on top of the
+# published semantics of torchvision's ConvNormActivation (conv no-bias, pad (k-1)//2, BN, SiLU),
+# SqueezeExcitation (avgpool -> 1x1+bias -> SiLU -> 1x1+bias -> sigmoid -> scale) and
+# StochasticDepth("row") (identity in eval or p=0).
+# ---------------------------------------------------------------------------------------------
+_EFF_BASE = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3), (6, 5, 1, 80, 112, 3),
+             (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+EFF_SCALING = {"efficientnet_b0": (1.0, 1.0), "efficientnet_b2": (1.1, 1.2), "efficientnet_b3": (1.2, 1.4)}
+
+
+def _divisible(v, d=8):
+    nv = max(d, int(v + d / 2) // d * d)
+    return nv + d if nv < 0.9 * v else nv
+
+
+def eff_table(arch):
+    w, dm = EFF_SCALING[arch]
+    return [(e, k, s, _divisible(ci * w), _divisible(co * w), int(math.ceil(n * dm))) for e, k, s, ci, co, n in _EFF_BASE]
+
+
+def _cna(sd, pfx, x, stride, groups, train, act=True):
+    w = sd[pfx + ".0.weight"]
+    y = _bn(sd, pfx + ".1", F.conv2d(x, w, None, stride, (w.shape[-1] - 1) // 2, 1, groups), train)
+    return F.silu(y) if act else y
+
+
+def eff_encoder(sd, x, arch, train):
+    x = _cna(sd, "features.0", x, 2, 1, train)
+    table = eff_table(arch)
+    for si, (e, k, s, cin, cout, n) in enumerate(table, start=1):
+        for b in range(n):
+            ci, st = (cin, s) if b == 0 else (cout, 1)
+            p = f"features.{si}.{b}.block"
+            h, li = x, 0
+            expanded = _divisible(ci * e)
+            if expanded != ci:
+                h = _cna(sd, f"{p}.{li}", h, 1, 1, train); li += 1
+            h = _cna(sd, f"{p}.{li}", h, st, expanded, train); li += 1
+            sc = F.adaptive_avg_pool2d(h, 1)
+            sc = F.silu(F.conv2d(sc, sd[f"{p}.{li}.fc1.weight"], sd[f"{p}.{li}.fc1.bias"]))
+            sc = torch.sigmoid(F.conv2d(sc, sd[f"{p}.{li}.fc2.weight"], sd[f"{p}.{li}.fc2.bias"]))
+            h = sc * h; li += 1
+            h = _cna(sd, f"{p}.{li}", h, 1, 1, train, act=False)
+            x = h + x if (st == 1 and ci == cout) else h          # stochastic depth: identity (eval / p = 0)
+    return _cna(sd, f"features.{len(table) + 1}", x, 1, 1, train)
+
+
+def eff_forward(sd, x, arch, mode, training=True):
+    """MILEfficientNet.forward (efficientnet.py:305-333); freeze_bn is a no-op there. Dropout = identity."""
+    feat = _pooled(eff_encoder(sd, x, arch, training))
+    if mode == "tile":
+        return F.linear(feat, sd["fc_tile.1.weight"], sd["fc_tile.1.bias"])
+    if mode == "image":
+        return (F.linear(feat, sd["fc_image_cls.2.weight"], sd["fc_image_cls.2.bias"]),
+                torch.relu(F.linear(feat, sd["fc_image_reg.2.weight"], sd["fc_image_reg.2.bias"])))
+    raise Exception("Something wrong in setmode.")

@@ -1,0 +1,153 @@
+"""GPU: MBConv kernels (depthwise conv, SE, stochastic-depth scale) and the EfficientNet models against the
+CPU oracle.  The oracle's EfficientNet branch is NOT pinned by the reference (torchvision 0.11.2 absent):
+these tests prove HIP == restated semantics, per-op against torch functional ops and end to end."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import functional as HF  # noqa: E402
+from cellsegmentation_amd import kernels as K  # noqa: E402
+from cellsegmentation_amd import synth  # noqa: E402
+from cellsegmentation_amd.model import efficientnet as EN  # noqa: E402
+from oracle import cellseg_oracle as orc  # noqa: E402
+
+
+def _nhwc(t, dtype, dev):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+
+
+def _nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(24, 3, 1, 15, 14), (40, 5, 2, 19, 19), (16, 3, 2, 10, 11), (48, 5, 1, 9, 9)])
+def test_depthwise_conv(cfg, dtype, dev):
+    C, k, s, H, W = cfg
+    torch.manual_seed(C + k)
+    x = torch.randn(2, C, H, W).to(dtype).float().requires_grad_()
+    w = (torch.randn(C, 1, k, k) / k).requires_grad_()
+    y = F.conv2d(x, w, None, s, (k - 1) // 2, 1, C)
+    dy = torch.randn_like(y).to(dtype).float()
+    y.backward(dy)
+    g = K.make_geom(2, H, W, C, C, k, k, s, (k - 1) // 2)
+    w_hwc = w.detach()[:, 0].permute(1, 2, 0).contiguous().to(dev)
+    xd, dyd = _nhwc(x.detach(), dtype, dev), _nhwc(dy, dtype, dev)
+    yd = K.dwconv_fwd(g, xd, w_hwc)
+    dxd = K.dwconv_dgrad(g, dyd, w_hwc)
+    dwd = K.dwconv_wgrad(g, xd, dyd)
+    sc, sh = torch.rand(C) + 0.5, torch.randn(C)
+    yf = K.dwconv_fwd(g, xd, w_hwc, sc.to(dev), sh.to(dev), K.CS_ACT_SILU)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert _rel(_nchw(yd), y.detach()) < tol
+    assert _rel(_nchw(dxd), x.grad) < tol
+    assert _rel(dwd.permute(2, 0, 1).unsqueeze(1).cpu(), w.grad) < 1e-4
+    assert _rel(_nchw(yf), F.silu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))) < tol
+
+
+def test_se_and_rowscale(dev):
+    torch.manual_seed(2)
+    N, C, Cs, H = 3, 48, 6, 7
+    x = torch.randn(N, C, H, H, requires_grad=True)
+    w1, b1 = torch.randn(Cs, C, 1, 1, requires_grad=True), torch.randn(Cs, requires_grad=True)
+    w2, b2 = torch.randn(C, Cs, 1, 1, requires_grad=True), torch.randn(C, requires_grad=True)
+    sc = torch.sigmoid(F.conv2d(F.silu(F.conv2d(F.adaptive_avg_pool2d(x, 1), w1, b1)), w2, b2))
+    y = sc * x
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xd, dyd = _nhwc(x.detach(), torch.float32, dev), _nhwc(dy, torch.float32, dev)
+    avg, _ = K.gap_fwd(xd, with_max=False)
+    W1, W2 = w1.detach().view(Cs, C).to(dev), w2.detach().view(C, Cs).to(dev)
+    h1, u1 = K.linear_fwd(avg, W1, b1.detach().to(dev), K.CS_ACT_SILU, want_preact=True)
+    s = K.linear_fwd(h1, W2, b2.detach().to(dev), K.CS_ACT_SIGMOID)
+    yd = K.se_scale(xd, s)
+    ds = K.se_scale_bwd_ds(dyd, xd)
+    dh1, dw2, db2 = K.linear_bwd(h1, W2, ds, s, K.CS_ACT_SIGMOID)
+    davg, dw1, db1 = K.linear_bwd(avg, W1, dh1, u1, K.CS_ACT_SILU)
+    dxd = K.se_scale_bwd_dx(dyd, s, davg)
+    torch.cuda.synchronize()
+    assert _rel(_nchw(yd), y.detach()) < 1e-5
+    assert _rel(_nchw(dxd), x.grad) < 1e-4
+    assert _rel(dw1.cpu(), w1.grad.view(Cs, C)) < 1e-4 and _rel(db1.cpu(), b1.grad) < 1e-4
+    assert _rel(dw2.cpu(), w2.grad.view(C, Cs)) < 1e-4 and _rel(db2.cpu(), b2.grad) < 1e-4
+    # StochasticDepth row scale + residual
+    a, b = torch.randn(N, H, H, C).to(dev), torch.randn(N, H, H, C).to(dev)
+    rs = torch.tensor([0.0, 1.25, 1.25], device=dev)
+    out = K.rowscale_add(a, rs, b)
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), (a * rs.view(-1, 1, 1, 1) + b).cpu()) < 1e-6
+
+
+def _pair(arch, dev, dtype=torch.float32):
+    m = {"efficientnet_b0": EN.MILefficientnetB0, "efficientnet_b2": EN.MILefficientnetB2, "efficientnet_b3": EN.MILefficientnetB3}[arch](
+        stochastic_depth_prob=0.0, num_classes=2)
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k, v in osd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    return m.to(dev).set_compute_dtype(dtype), osd
+
+
+@pytest.mark.parametrize("arch,size,n", [("efficientnet_b0", 64, 4), ("efficientnet_b3", 96, 2)])
+def test_efficientnet_tile_and_image_vs_oracle(arch, size, n, dev):
+    x = synth.normalise(synth.ihc_tiles(n, size, 51))
+    labels = torch.tensor([i % 2 for i in range(n)])
+    m, osd = _pair(arch, dev)
+    # eval inference
+    m.setmode("tile")
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(x.to(dev))
+    ref_eval = orc.eff_forward(osd, x, arch, "tile", training=False).detach()
+    assert _rel(out_eval.cpu(), ref_eval) < 1e-4
+    # --scratch style training step (BN batch statistics: freeze_bn is a no-op for this family)
+    m.train()
+    m.set_encoder_grads(True)
+    loss = HF.cross_entropy(m(x.to(dev), freeze_bn=True), labels.to(dev))
+    loss.backward()
+    ref = F.cross_entropy(orc.eff_forward(osd, x, arch, "tile", training=True), labels)
+    ref.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    worst = []
+    for k, p in m.named_parameters():
+        if p.grad is None or osd[k].grad is None:
+            continue
+        worst.append((_rel(p.grad.cpu(), osd[k].grad), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-2, worst[:5]
+    assert float(np.median([w for w, _ in worst])) < 1e-3
+    bufs = dict(m.named_buffers())
+    assert _rel(bufs["features.0.1.running_var"].cpu(), osd["features.0.1.running_var"]) < 1e-5
+
+
+def test_efficientnet_bf16_and_api(dev):
+    m, osd = _pair("efficientnet_b0", dev, torch.bfloat16)
+    x = synth.normalise(synth.ihc_tiles(2, 64, 53))
+    m.setmode("image")
+    m.eval()
+    with torch.no_grad():
+        c, r = m(x.to(dev))
+    rc, rr = orc.eff_forward(osd, x, "efficientnet_b0", "image", training=False)
+    assert tuple(c.shape) == (2, 7) and tuple(r.shape) == (2, 1)
+    assert _rel(c.float().cpu(), rc.detach()) < 6e-2
+    with pytest.raises(Exception, match="Invalid mode"):
+        m.setmode("nope")
+    m.setmode("segment")
+    with pytest.raises(Exception):
+        m(x.to(dev))
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad) == []     # segment mode freezes everything it can
