@@ -123,13 +123,18 @@ def test_efficientnet_tile_and_image_vs_oracle(arch, size, n, dev):
     ref.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    # Error per tensor relative to max(|ref tensor|, 1e-4 * largest gradient of the net): the bias of a BN that feeds
+    # another train-mode BN has an analytically ZERO gradient (a per-channel constant is normalised away); the reference
+    # value is ~1e-7 rounding noise there, so a purely per-tensor relative error would be meaningless.
+    gmax = max(float(v.grad.abs().max()) for v in osd.values() if v.grad is not None)
     worst = []
     for k, p in m.named_parameters():
         if p.grad is None or osd[k].grad is None:
             continue
-        worst.append((_rel(p.grad.cpu(), osd[k].grad), k))
+        g, r = p.grad.cpu(), osd[k].grad
+        worst.append((float((g - r).abs().max() / max(float(r.abs().max()), 1e-4 * gmax)), k))
     worst.sort(reverse=True)
-    assert worst[0][0] < 2e-2, worst[:5]
+    assert worst[0][0] < 5e-3, worst[:5]
     assert float(np.median([w for w, _ in worst])) < 1e-3
     bufs = dict(m.named_buffers())
     assert _rel(bufs["features.0.1.running_var"].cpu(), osd["features.0.1.running_var"]) < 1e-5
@@ -150,4 +155,5 @@ def test_efficientnet_bf16_and_api(dev):
     m.setmode("segment")
     with pytest.raises(Exception):
         m(x.to(dev))
-    assert sorted(k for k, p in m.named_parameters() if p.requires_grad) == []     # segment mode freezes everything it can
+    # segment mode freezes every group setmode() knows; `classifier` is never toggled (neither does the reference)
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad) == ["classifier.1.bias", "classifier.1.weight"]
