@@ -44,6 +44,9 @@ struct IgemmParams {
     // destination sub-grid (strided data-gradient parity classes): pixel (n, a*dst_step+dst_oy, b*dst_step+dst_ox) of a
     // DHF x DWF tensor; dst_step == 1 means rows map to pixels one-to-one
     int dst_step, dst_oy, dst_ox, DHF, DWF;
+    // grouped convolution as slab-dense GEMM: the 64-wide destination-channel tile n0 contracts only over source
+    // channels [n0, n0+64) (block-diagonal weights inside the slab); SCc is then 8 while SC stays the pixel stride
+    int cslab;
     long long M;      // N*DH*DW
     long long src_pixels;   // N*SH*SW
     int Qtot;         // R*S*SCc (taps walked by this launch)
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             }
         }
     }
+    const int slab0 = p.cslab ? (n0 / 64) * 8 : 0;      // first source chunk of this tile's channel slab
     // walking position of this thread's chunk column in K space
     int q = lc;
     int tap = q / p.SCc;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             }
         } else if constexpr (MODE == 1) {
             const int t = kh * p.S + kw;
-            const long long toff = ((long long)(p.sgn * kh) * p.SW + p.sgn * kw) * p.SC + cc * CE;
+            const long long toff = ((long long)(p.sgn * kh) * p.SW + p.sgn * kw) * p.SC + (cc + slab0) * CE;
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 uint4 v = make_uint4(0, 0, 0, 0);
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
             }
         }
     }
+    const int slab0 = p.cslab ? (n0 / 64) * 8 : 0;
     int q = lc;
     int tap = q / p.SCc;
     int cc = q - tap * p.SCc;
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
             for (int i = 0; i < AI; ++i) va[i] = (qok && vmask[i]) ? (unsigned)(rbase[i] + q * 16) : OOB;
         } else if constexpr (MODE == 1) {
             const int t = kh * p.S + kw;
-            const int toff = ((p.sgn * kh) * p.SW + p.sgn * kw) * p.SC * ES + cc * 16;
+            const int toff = ((p.sgn * kh) * p.SW + p.sgn * kw) * p.SC * ES + (cc + slab0) * 16;
 #pragma unroll
             for (int i = 0; i < AI; ++i) va[i] = (qok && ((vmask[i] >> t) & 1ull)) ? (unsigned)(rbase[i] + toff) : OOB;
         } else {
@@ -560,11 +565,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
 
 int igemm_mode(const IgemmParams& p) {
     if (p.div > 1) return 2;
-    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0 && p.off0x == 0 && p.wkstep == 1 && p.dst_step == 1) return 0;
+    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0 && p.off0x == 0 && p.wkstep == 1 && p.dst_step == 1 && !p.cslab) return 0;
     return p.R * p.S <= 64 ? 1 : 2;
 }
 
@@ -609,7 +615,8 @@ int igemm_tile(long long M, int NOUT) {
 template <typename T>
 int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream_t st) {
     int rc;
-    const int tile = igemm_tile(p.M, p.NOUT);
+    int tile = igemm_tile(p.M, p.NOUT);
+    if (p.cslab) tile = (p.M + 127) / 128 >= 384 ? 128064 : 64064;   // one 64-channel slab per N tile
     switch (tile) {
         case 128128: rc = launch_igemm<T, 128, 128>(p, st); break;
         case 64128: rc = launch_igemm<T, 64, 128>(p, st); break;
@@ -645,18 +652,24 @@ int check_geom(const CsConvGeom* g, int dtype) {
 }  // namespace
 
 extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_out); }
+/* The next cs_conv2d_fwd / _dgrad / _wgrad call issued by this thread treats the convolution as GROUPED
+ * (groups = C / channels_per_group, C == K, C % 64 == 0) in slab-dense form; see cs_weight_prep_grouped. */
+extern "C" int cs_conv2d_next_is_grouped(void) { g_next_slab = 1; return CS_OK; }
 extern "C" int cs_set_igemm_path(int path) { const int old = g_igemm_path; g_igemm_path = path; return old; }
 
 extern "C" size_t cs_conv2d_stats_workspace(long long M, int n_out) {
-    const int bm = igemm_tile(M, n_out) / 1000;
-    return (size_t)((M + bm - 1) / bm) * 2 * (size_t)n_out * sizeof(float);
+    // one partial row per M tile; sized for the smallest tile height (64) so every dispatch variant fits
+    return (size_t)((M + 63) / 64 + 4) * 2 * (size_t)n_out * sizeof(float);
 }
 
 extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
                              const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
                              void* stream) {
+    const int slab = g_next_slab;
+    g_next_slab = 0;
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
+    if (slab) CS_CHECK_ARG(g->C % 64 == 0 && g->K == g->C, "grouped conv: width must be a multiple of 64 and C == K");
     CS_CHECK_ARG(x && w_khwc && y, "conv2d_fwd: NULL tensor");
     CS_CHECK_ARG(!stats || workspace, "conv2d_fwd: stats need a workspace of cs_conv2d_stats_workspace() bytes");
     IgemmParams p{};
@@ -674,6 +687,8 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     p.M = (long long)g->N * g->P * g->Q;
     p.src_pixels = (long long)g->N * g->H * g->W;
     p.SCc = g->C / ce;
+    p.cslab = slab;
+    if (slab) p.SCc = 64 / ce;
     p.Qtot = g->R * g->S * p.SCc;
     p.wrow_chunks = p.Qtot;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -682,8 +697,11 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
 
 extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                                const void* mask, void* dx, float* colsum, void* workspace, void* stream) {
+    const int slab = g_next_slab;
+    g_next_slab = 0;
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
+    if (slab) CS_CHECK_ARG(g->C % 64 == 0 && g->K == g->C, "grouped conv: width must be a multiple of 64 and C == K");
     CS_CHECK_ARG(dy && w_chwk && dx, "conv2d_dgrad: NULL tensor");
     CS_CHECK_ARG(!colsum || workspace, "conv2d_dgrad: colsum needs a workspace of cs_conv2d_stats_workspace() bytes");
     const int ce = dtype == CS_F32 ? 4 : 8;
@@ -703,6 +721,8 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     p.M = (long long)g->N * g->H * g->W;
     p.src_pixels = (long long)g->N * g->P * g->Q;
     p.SCc = g->K / ce;
+    p.cslab = slab;
+    if (slab) p.SCc = 64 / ce;
     p.Qtot = g->R * g->S * p.SCc;
     p.wrow_chunks = p.Qtot;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -757,7 +777,9 @@ struct WgradParams {
     int KO;
     int R, S, stride, pad;
     long long M;
-    int QE;           // R*S*C (elements)
+    int QE;           // R*S*Cq (elements of one dW row)
+    int Cq;           // channels per tap in dW's K space: C, or 64 for slab-dense grouped convolution
+    int slab;         // grouped: output-channel tile k0 (BM == 64) reads source channels [k0, k0+64)
     int SCc;          // C / chunk
     long long m_per_split;   // multiple of the K-step
 };
@@ -809,8 +831,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const bool b_ok = bq < p.QE;
     int b_kh = 0, b_kw = 0, b_c = 0;
     if (b_ok) {
-        const int tap = bq / p.C;
-        b_c = bq - tap * p.C;
+        const int tap = bq / p.Cq;
+        b_c = bq - tap * p.Cq + (p.slab ? k0 : 0);
         b_kh = tap / p.S;
         b_kw = tap - b_kh * p.S;
     }
@@ -1010,8 +1032,11 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
 
 extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                                int use_tr_read, void* stream) {
+    const int slab = g_next_slab;
+    g_next_slab = 0;
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
+    if (slab) CS_CHECK_ARG(g->C % 64 == 0 && g->K == g->C, "grouped conv: width must be a multiple of 64 and C == K");
     CS_CHECK_ARG(x && dy && dw_khwc, "conv2d_wgrad: NULL tensor");
     WgradParams p{};
     const int ce = dtype == CS_F32 ? 4 : 8;
@@ -1020,17 +1045,20 @@ extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     p.P = g->P; p.Q = g->Q; p.KO = g->K;
     p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
     p.M = (long long)g->N * g->P * g->Q;
-    p.QE = g->R * g->S * g->C;
+    p.Cq = slab ? 64 : g->C;
+    p.slab = slab;
+    p.QE = g->R * g->S * p.Cq;
     p.SCc = g->C / ce;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool wide = g->K > 64 && !slab;      // slab mode: one 64-channel slab per M tile
     if (dtype == CS_F32) {
-        if (g->K > 64) return launch_wgrad<float, 128, 128, false>(p, st);
+        if (wide) return launch_wgrad<float, 128, 128, false>(p, st);
         return launch_wgrad<float, 64, 128, false>(p, st);
     }
     if (use_tr_read) {
-        if (g->K > 64) return launch_wgrad<bf16_t, 128, 128, true>(p, st);
+        if (wide) return launch_wgrad<bf16_t, 128, 128, true>(p, st);
         return launch_wgrad<bf16_t, 64, 128, true>(p, st);
     }
-    if (g->K > 64) return launch_wgrad<bf16_t, 128, 128, false>(p, st);
+    if (wide) return launch_wgrad<bf16_t, 128, 128, false>(p, st);
     return launch_wgrad<bf16_t, 64, 128, false>(p, st);
 }

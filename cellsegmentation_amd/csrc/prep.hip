@@ -101,6 +101,67 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// ---- grouped weights: fp32 [K][Cg][R][S] (x scale[k]) -> slab-dense T [K][R][S][64] and T [C][R][S][64]
+// (K == C, groups of Cg channels, 64-channel slabs; entries outside a channel's own group are zero)
+template <typename T>
+__global__ void weight_prep_grouped_kernel(const float* __restrict__ w, const float* __restrict__ scale, int K, int Cg, int R, int S,
+                                           T* __restrict__ w_khwc, T* __restrict__ w_chwk) {
+    const int RS = R * S;
+    const long long total = (long long)K * RS * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(idx % 64);                 // slab-local channel on the contracted side
+        const int rs = (int)((idx / 64) % RS);
+        const int row = (int)(idx / (64LL * RS));      // k for w_khwc, c for w_chwk
+        const int slab = row / 64;
+        const int row_l = row % 64;
+        const bool same = (row_l / Cg) == (l / Cg);
+        if (w_khwc) {
+            float v = 0.f;
+            if (same) { v = w[((long long)row * Cg + (l % Cg)) * RS + rs]; if (scale) v *= scale[row]; }
+            w_khwc[idx] = from_f32<T>(v);
+        }
+        if (w_chwk) {
+            float v = 0.f;
+            const int k = slab * 64 + l;
+            if (same) { v = w[((long long)k * Cg + (row_l % Cg)) * RS + rs]; if (scale) v *= scale[k]; }
+            w_chwk[idx] = from_f32<T>(v);
+        }
+    }
+}
+
+// dw[k][cg][r][s] = scale[k] * raw[k][r][s][base(k)+cg] with base(k) = ((k%64)/Cg)*Cg; BN-eval parameter grads as in
+// wgrad_finalize_kernel.  One workgroup per k.
+__global__ __launch_bounds__(256) void wgrad_finalize_grouped_kernel(const float* __restrict__ raw, const float* __restrict__ w,
+                                                                     const float* scale, const float* rstd, const float* mean,
+                                                                     const float* gsum, int Cg, int R, int S, float* __restrict__ dw,
+                                                                     float* dgamma, float* dbeta) {
+    const int k = blockIdx.x;
+    const int RS = R * S;
+    const int per = Cg * RS;
+    const int base = ((k % 64) / Cg) * Cg;
+    const float sc = scale ? scale[k] : 1.f;
+    float dot = 0.f;
+    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+        const int c = j / RS, rs = j - c * RS;
+        const float r = raw[((long long)k * RS + rs) * 64 + base + c];
+        const long long o = (long long)k * per + j;
+        if (dgamma) dot += w[o] * r;
+        dw[o] = sc * r;
+    }
+    if (dgamma || dbeta) {
+        __shared__ float red[4];
+        dot = wave_sum(dot);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = red[0] + red[1] + red[2] + red[3];
+            const float gs = gsum ? gsum[k] : 0.f;
+            if (dgamma) dgamma[k] = rstd[k] * (tot - mean[k] * gs);
+            if (dbeta) dbeta[k] = gs;
+        }
+    }
+}
+
 // ---- wgrad finalize: one workgroup per output channel k --------------------------------------
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ dw_khwc, const float* __restrict__ w,
                                                              const float* scale, const float* rstd, const float* mean,
@@ -277,6 +338,37 @@ extern "C" int cs_colsum(const void* g, int dtype, long long M, int C, float* ou
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, M, C, out, (int)rows);
     else
         CS_CHECK_ARG(false, "colsum: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_weight_prep_grouped(const float* w, const float* scale, int dtype, int K, int Cg, int R, int S, void* w_khwc,
+                                      void* w_chwk, void* stream) {
+    CS_CHECK_ARG(w && (w_khwc || w_chwk), "weight_prep_grouped: NULL tensor");
+    CS_CHECK_ARG(K > 0 && K % 64 == 0 && Cg > 0 && 64 % Cg == 0 && R > 0 && S > 0, "weight_prep_grouped: need K % 64 == 0 and Cg | 64");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)K * R * S * 64;
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(weight_prep_grouped_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, scale, K, Cg, R, S,
+                           (float*)w_khwc, (float*)w_chwk);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(weight_prep_grouped_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, scale, K, Cg, R, S,
+                           (bf16_t*)w_khwc, (bf16_t*)w_chwk);
+    else
+        CS_CHECK_ARG(false, "weight_prep_grouped: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_wgrad_finalize_grouped(const float* dw_slab, const float* w, const float* scale, const float* rstd, const float* mean,
+                                         const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma, float* dbeta,
+                                         void* stream) {
+    CS_CHECK_ARG(dw_slab && dw && K > 0 && Cg > 0 && 64 % Cg == 0, "wgrad_finalize_grouped: bad arguments");
+    CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum), "wgrad_finalize_grouped: dgamma needs w, rstd, mean, gsum");
+    CS_CHECK_ARG(!dbeta || gsum, "wgrad_finalize_grouped: dbeta needs gsum");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(wgrad_finalize_grouped_kernel, dim3(K), dim3(256), 0, st, dw_slab, w, scale, rstd, mean, gsum, Cg, R, S, dw, dgamma,
+                       dbeta);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -35,8 +35,12 @@ class ConvUnit:
     def __init__(self, name, conv, bn, act, src, dst, res=None):
         self.name, self.conv, self.bn, self.act = name, conv, bn, act
         self.src, self.dst, self.res = src, dst, res
-        if conv.groups != 1:
-            raise NotImplementedError(f"{name}: grouped convolution is not on the HIP path yet")
+        self.grouped = conv.groups != 1
+        if self.grouped:
+            cg = conv.in_channels // conv.groups
+            if conv.in_channels != conv.out_channels or conv.in_channels % 64 != 0 or 64 % cg != 0 or conv.bias is not None:
+                raise NotImplementedError(f"{name}: grouped convolution needs C == K, C % 64 == 0, (C/groups) | 64, no bias "
+                                          "(the ResNeXt 32x4d / 32x8d 3x3 layers)")
         self._cache = None
 
     def params(self):
@@ -185,7 +189,10 @@ def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded):
         scale, shift, rstd = K.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bias)
     else:
         shift = bias
-    w_khwc, w_chwk = K.weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=need_bwd)
+    if u.grouped:
+        w_khwc, w_chwk = K.weight_prep_grouped(w, scale, dtype, want_fwd=True, want_bwd=need_bwd)
+    else:
+        w_khwc, w_chwk = K.weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=need_bwd)
     staged = SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=_pad_vec(shift, Kp), rstd=rstd)
     u._cache = (key, staged)
     return staged
@@ -221,12 +228,12 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             batch_stats = _bn_uses_batch_stats(u.bn, bn_train)
             st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats)
             if not batch_stats:
-                y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act)
+                y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=False)
             else:
                 bn = u.bn
                 stats = K.new_stats(Kp, x.device)
-                z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats)
+                z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats, grouped=u.grouped)
                 M = N * geom.P * geom.Q
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 mean, rstd = K.bn_finalize(stats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
@@ -368,17 +375,22 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum = K.colsum(dz)
                     if not a.train and u.res is not None and grads.get(u.res) is g:
                         gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
-                raw = torch.zeros((geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
-                K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read)
+                raw = torch.zeros((geom.K, geom.R, geom.S, 64 if u.grouped else geom.C), dtype=torch.float32, device=x.device)
+                K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
                 dw = torch.empty_like(conv.weight)
                 dbias = torch.empty_like(conv.bias) if want_b else None
                 dgamma = dbeta = None
                 if want_bn and not a.train:
                     dgb = torch.empty((2, Kc), dtype=torch.float32, device=x.device)
                     dgamma, dbeta = dgb[0], dgb[1]
-                K.wgrad_finalize(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
-                                 None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, Cin, dw,
-                                 dbias=dbias, dgamma=dgamma, dbeta=dbeta)
+                if u.grouped:
+                    K.wgrad_finalize_grouped(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
+                                             None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, dw,
+                                             dgamma=dgamma, dbeta=dbeta)
+                else:
+                    K.wgrad_finalize(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
+                                     None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, Cin, dw,
+                                     dbias=dbias, dgamma=dgamma, dbeta=dbeta)
                 if want_w:
                     pgrads[pindex[(ui, "weight")]] = dw
                 if want_b:
@@ -395,7 +407,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 pending = grads.pop(u.src, None)
                 mask = x if (u.src in plan.relu_slots and final) else None
                 cs = torch.zeros((geom.C,), dtype=torch.float32, device=x.device) if final else None
-                dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs)
+                dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs, grouped=u.grouped)
                 grads[u.src] = dx
                 if final:
                     gsum_cache[u.src] = cs

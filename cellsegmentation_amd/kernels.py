@@ -139,9 +139,31 @@ def igemm_tile(M, n_out):
     return v // 1000, v % 1000
 
 
-def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None):
+def weight_prep_grouped(w, scale, dtype, want_fwd=True, want_bwd=False):
+    """w[K][Cg][R][S] (groups = K // Cg... i.e. Conv2d(groups=G).weight) -> slab-dense operands [K][R][S][64]."""
+    K_, Cg, R, S = w.shape
+    w_khwc = torch.empty((K_, R, S, 64), dtype=dtype, device=w.device) if want_fwd else None
+    w_chwk = torch.empty((K_, R, S, 64), dtype=dtype, device=w.device) if want_bwd else None
+    _lib.check(_lib.load().cs_weight_prep_grouped(_p(w), _p(scale), _code(dtype), K_, Cg, R, S, _p(w_khwc), _p(w_chwk), _stream()),
+               "weight_prep_grouped")
+    return w_khwc, w_chwk
+
+
+def wgrad_finalize_grouped(dw_slab, w, scale, rstd, mean, gsum, dw, dgamma=None, dbeta=None):
+    K_, Cg, R, S = dw.shape
+    _lib.check(_lib.load().cs_wgrad_finalize_grouped(_p(dw_slab), _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K_, Cg, R, S, _p(dw),
+                                                     _p(dgamma), _p(dbeta), _stream()), "wgrad_finalize_grouped")
+
+
+def _mark_grouped(grouped):
+    if grouped:
+        _lib.load().cs_conv2d_next_is_grouped()
+
+
+def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None, grouped=False):
     y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
     lib = _lib.load()
+    _mark_grouped(grouped)
     ws = _stats_ws(geom.N * geom.P * geom.Q, geom.K, x.device) if stats is not None else None
     _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd(
         ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(stats), _p(ws),
@@ -149,9 +171,10 @@ def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_
     return y
 
 
-def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None):
+def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False):
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
+    _mark_grouped(grouped)
     ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if colsum is not None else None
     _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
         ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _p(ws), _stream())),
@@ -159,9 +182,10 @@ def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None):
     return dx
 
 
-def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True):
-    """dw_raw[K,R,S,Cp] fp32 (pre-zeroed) += wgrad."""
+def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
+    """dw_raw[K,R,S,Cp] fp32 (pre-zeroed) += wgrad (grouped: [K,R,S,64] slab-dense)."""
     lib = _lib.load()
+    _mark_grouped(grouped)
     _lib.check(_timed("wgrad", geom, x.dtype, lambda: lib.cs_conv2d_wgrad(
         ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw_raw), 1 if use_tr_read else 0, _stream())), "conv2d_wgrad")
     return dw_raw

@@ -17,13 +17,15 @@ from .. import engine as E
 from .. import functional as HF
 from .. import kernels as K
 
-__all__ = ["MILResNet", "MILresnet18", "MILresnet34", "MILresnet50"]
+__all__ = ["MILResNet", "MILresnet18", "MILresnet34", "MILresnet50", "MILresnext50_32x4d", "MILresnext101_32x8d"]
 
 # name -> (block kind, blocks per stage)            model/resnet.py:336-361
 _ARCH = {
     "resnet18": ("basic", (2, 2, 2, 2)),
     "resnet34": ("basic", (3, 4, 6, 3)),
     "resnet50": ("bottleneck", (3, 4, 6, 3)),
+    "resnext50_32x4d": ("bottleneck", (3, 4, 6, 3)),          # model/resnext.py:418-442
+    "resnext101_32x8d": ("bottleneck", (3, 4, 23, 3)),
 }
 # per block kind: expansion and the (kernel, padding, carries-stride) of its convs, in order
 _BLOCK = {
@@ -74,7 +76,8 @@ def _upsample_conv(cin, cout):
 
 
 class MILResNet(nn.Module):
-    def __init__(self, encoder, num_classes=1000, groups=1, width_per_group=64, block_table=None, decoder_expansion=None):
+    def __init__(self, encoder, num_classes=1000, groups=1, width_per_group=64, block_table=None, decoder_expansion=None,
+                 fan_out_init=False):
         super().__init__()
         kind, depths = (block_table or _ARCH)[encoder]
         exp = _BLOCK[kind][0]
@@ -120,8 +123,11 @@ class MILResNet(nn.Module):
             setattr(self, f"upconv{i}", _upsample_conv(ci, co))
         self.seg_out_conv = nn.Conv2d(64, 2, 1)
 
-        for m in self.modules():                      # model/resnet.py:170-177
+        for m in self.modules():                      # model/resnet.py:170-177 ; model/resnext.py:223-230 (fan_out, bias untouched)
             if isinstance(m, nn.Conv2d):
+                if fan_out_init:
+                    nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                    continue
                 nn.init.kaiming_normal_(m.weight)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
@@ -308,3 +314,14 @@ def MILresnet34(pretrained=False, **kwargs):
 
 def MILresnet50(pretrained=False, **kwargs):
     return _make("resnet50", pretrained, **kwargs)
+
+
+def MILresnext50_32x4d(pretrained=False, progress=True, **kwargs):
+    """model/resnext.py:418-429.  The decoder of the reference's ResNeXt is built for expansion 1 (resnext.py:209-217), so
+    segment mode cannot run there either; tile / image modes only."""
+    return _make("resnext50_32x4d", pretrained, groups=32, width_per_group=4, decoder_expansion=1, fan_out_init=True, **kwargs)
+
+
+def MILresnext101_32x8d(pretrained=False, progress=True, **kwargs):
+    """model/resnext.py:431-442"""
+    return _make("resnext101_32x8d", pretrained, groups=32, width_per_group=8, decoder_expansion=1, fan_out_init=True, **kwargs)

@@ -120,6 +120,19 @@ int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* d
 int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, const float* rstd,
                       const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp,
                       float* dw, float* dbias, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* ---- grouped 3x3 convolution (ResNeXt, model/resnext.py:16-19,85: groups=32) in slab-dense form ------------
+ * C == K, C % 64 == 0, Cg = C/groups divides 64.  Each 64-channel destination tile contracts only over its
+ * own 64 source channels with weights that are block-diagonal inside the slab:
+ *   cs_weight_prep_grouped: w[K][Cg][R][S] fp32 -> w_khwc[K][R][S][64], w_chwk[C][R][S][64]
+ *   cs_conv2d_next_is_grouped(): marks the NEXT cs_conv2d_fwd/_dgrad/_wgrad call of this thread as grouped
+ *     (same signatures; dw buffer of wgrad is [K][R][S][64] fp32)
+ *   cs_wgrad_finalize_grouped: picks the group diagonal out of the slab gradient -> dw[K][Cg][R][S] (+BN-eval grads) */
+int cs_weight_prep_grouped(const float* w, const float* scale, int dtype, int K, int Cg, int R, int S, void* w_khwc,
+                           void* w_chwk, void* stream);
+int cs_conv2d_next_is_grouped(void);
+int cs_wgrad_finalize_grouped(const float* dw_slab, const float* w, const float* scale, const float* rstd, const float* mean,
+                              const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma, float* dbeta,
+                              void* stream);
 /* per-channel column sums: out[c] (+)= sum_m g[m][c]; fp32 out, zeroed by the caller. */
 int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream);
 

@@ -156,3 +156,29 @@ def test_bn_fold_and_finalize_bn_grads(dev):
     assert _relerr(dw.cpu(), w.grad) < 1e-4
     assert _relerr(dgamma.cpu(), gamma.grad) < 1e-4
     assert _relerr(dbeta.cpu(), beta.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 19, 19, 128, 32, 1), (2, 19, 19, 128, 32, 2), (1, 10, 10, 256, 32, 1), (1, 9, 9, 256, 8, 2)])
+def test_grouped_conv_slab_dense(cfg, dtype, dev, igemm_path):
+    """ResNeXt grouped 3x3 (groups=32 / widths 128, 256; and a Cg=32 case) vs F.conv2d(groups=...)."""
+    N, H, W, C, G, s = cfg
+    g = torch.Generator().manual_seed(C + G + s)
+    x = _q(torch.randn((N, C, H, W), generator=g), dtype).requires_grad_()
+    w = _q(torch.randn((C, C // G, 3, 3), generator=g) / (9 * C / G) ** 0.5, dtype).requires_grad_()
+    y = F.conv2d(x, w, None, s, 1, 1, G)
+    dy = _q(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    geom = K.make_geom(N, H, W, C, C, 3, 3, s, 1)
+    xd, dyd = _nhwc(x.detach(), dtype, dev), _nhwc(dy, dtype, dev)
+    wk, wc = K.weight_prep_grouped(w.detach().to(dev), None, dtype, True, True)
+    yd = K.conv_fwd(geom, xd, wk, grouped=True)
+    dxd = K.conv_dgrad(geom, dyd, wc, grouped=True)
+    raw = torch.zeros((C, 3, 3, 64), dtype=torch.float32, device=dev)
+    K.conv_wgrad(geom, xd, dyd, raw, grouped=True)
+    dw = torch.empty_like(w.detach()).to(dev)
+    K.wgrad_finalize_grouped(raw, None, None, None, None, None, dw)
+    torch.cuda.synchronize()
+    assert _relerr(_from_nhwc(yd, C), y.detach()) < TOL[dtype]
+    assert _relerr(_from_nhwc(dxd, C), x.grad) < TOL[dtype]
+    assert _relerr(dw.cpu(), w.grad) < (1e-4 if dtype == torch.float32 else 2e-3)

@@ -16,7 +16,7 @@ from cellsegmentation_amd import functional as HF  # noqa: E402
 from cellsegmentation_amd.model import resnet as R  # noqa: E402
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"), allow_pickle=False)
-FACT = {"resnet18": R.MILresnet18, "resnet34": R.MILresnet34, "resnet50": R.MILresnet50}
+FACT = {"resnet18": R.MILresnet18, "resnet34": R.MILresnet34, "resnet50": R.MILresnet50, "resnext50_32x4d": R.MILresnext50_32x4d}
 RTOL = 1e-4          # logits / loss / probabilities (north_star tolerance)
 GTOL = 5e-3          # gradients: ~3x the reference's own fp32-vs-fp64 noise (1.5e-3, tests/golden/measure_fp32_noise.py)
 # train-mode BN makes gradients far worse conditioned (36 samples/channel in layer4 at 96x96): measured noise of the
@@ -73,7 +73,8 @@ def check_grads(tag, params, errs, rtol, keys=None):
             errs.append(f"grad {name}: abs-sum {d_got[1]:.6e} vs {d_want[1]:.6e}")
 
 
-@pytest.mark.parametrize("arch,size", [("resnet18", 32), ("resnet18", 299), ("resnet34", 64), ("resnet50", 32), ("resnet50", 299)])
+@pytest.mark.parametrize("arch,size", [("resnet18", 32), ("resnet18", 299), ("resnet34", 64), ("resnet50", 32), ("resnet50", 299),
+                                       ("resnext50_32x4d", 64)])
 def test_tile_mode_matches_reference_fp32(arch, size, dev):
     tag = f"{arch}/tile{size}"
     n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])
