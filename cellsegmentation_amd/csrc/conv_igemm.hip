@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             }
         }
     }
-    const int slab0 = p.cslab ? (n0 / 64) * 8 : 0;      // first source chunk of this tile's channel slab
+    const int slab0 = p.cslab ? (n0 / 64) * (64 / CE) : 0;      // first source chunk of this tile's channel slab
     // walking position of this thread's chunk column in K space
     int q = lc;
     int tap = q / p.SCc;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
             }
         }
     }
-    const int slab0 = p.cslab ? (n0 / 64) * 8 : 0;
+    const int slab0 = p.cslab ? (n0 / 64) * (4 * ES) : 0;      // 64 channels = 4*sizeof(T) chunks of 16 bytes
     int q = lc;
     int tap = q / p.SCc;
     int cc = q - tap * p.SCc;
