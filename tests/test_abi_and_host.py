@@ -59,7 +59,23 @@ def test_forward_errors():
     assert any("upconv3.0.weight".startswith(p) for p in m.seg_module_prefix)
 
 
-@pytest.mark.parametrize("arch", ["resnet18", "resnet34", "resnet50"])
+def test_efficientnet_structure():
+    from cellsegmentation_amd.model import efficientnet as EN
+    b0 = nets["efficientnet_b0"]
+    # torchvision efficientnet_b0: 5,288,548 parameters of which 1,281,000 in the 1000-way classifier
+    assert sum(p.numel() for p in b0.features.parameters()) == 4007548
+    assert b0.feature_dim == 1280 and nets["efficientnet_b2"].feature_dim == 1408 and nets["efficientnet_b3"].feature_dim == 1536
+    assert EN.mbconv_table(1.2, 1.4)[0][3:] == (40, 24, 2)         # B3 stem 40, first stage 24 x2
+    assert [c[4] for c in EN.mbconv_table(1.1, 1.2)] == [16, 24, 48, 88, 120, 208, 352]
+    keys = b0.state_dict().keys()
+    assert "features.1.0.block.1.fc1.weight" in keys and "features.8.1.running_var" in keys and "fc_image_reg.2.bias" in keys
+    b0.setmode("image")
+    assert all(p.requires_grad for p in b0.features.parameters()) and not b0.fc_tile[1].weight.requires_grad
+    with pytest.raises(Exception, match="Invalid mode"):
+        b0.setmode("x")
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet34", "resnet50", "resnext50_32x4d", "resnext101_32x8d"])
 def test_state_dict_names_and_shapes(arch):
     m = nets[arch]
     want = {k: tuple(v.shape) for k, v in orc.empty_state_dict(arch).items()}
@@ -69,7 +85,9 @@ def test_state_dict_names_and_shapes(arch):
 
 
 def test_nets_keys():
-    assert {"resnet18", "resnet34", "resnet50"} <= set(nets.keys())
+    # every key of the reference's dict (model/__init__.py:5-13) + efficientnet_b3 (BASELINE config 4)
+    assert {"resnet18", "resnet34", "resnet50", "efficientnet_b0", "efficientnet_b2", "resnext50_32x4d", "resnext101_32x8d",
+            "efficientnet_b3"} == set(nets.keys())
     with pytest.raises(KeyError):
         nets["vgg16"]
 
