@@ -20,6 +20,7 @@
 // Epilogue: accumulators -> LDS (fp32) -> 8 channels per thread, fully vectorised
 // scale/shift/residual/activation/mask + store + optional per-channel statistics.
 #include "cs_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -83,21 +84,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
     // ---- epilogue: accumulators -> LDS fp32 [BM][BN] (aliases the staging buffers) ----
+    // Two passes over the tile rows (wm = 0 half, then wm = 1 half) so the fp32 staging image is only
+    // (BM/2) x BN: halves the epilogue's LDS footprint -> more workgroups per CU on the 1-K-step (HBM-bound) convs.
     float* Cs = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int col = wn * (BN / 2) + j * 32 + l31;
-                Cs[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
-
     constexpr int CG = BN / 8;              // 8-channel groups per tile row
-    constexpr int ITERS = BM * BN / 8 / 256;
+    constexpr int HROWS = BM / 2;
+    constexpr int ITERS = HROWS * BN / 8 / 256;
     const int cg = tid % CG;
     const int o = n0 + cg * 8;
     const bool ook = o < p.NOUT;
@@ -114,53 +106,71 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
     const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
     const T* __restrict__ msk = reinterpret_cast<const T*>(p.mask);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = it * (256 / CG) + tid / CG;
-        const long long m = m0 + row;
-        if (m < p.M && ook) {
-            float v[8];
-            const float4 c0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
-            const float4 c1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
-            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
-            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-            long long dpix = m;
-            if (p.dst_step != 1) {
-                const long long img = m / ((long long)p.DH * p.DW);
-                const int rem = (int)(m - img * (long long)p.DH * p.DW);
-                const int a = rem / p.DW;
-                const int b = rem - a * p.DW;
-                dpix = (img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox;
-            }
-            const long long off = dpix * p.NOUT + o;
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        if (wm == half) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-            if (res) {
-                float r8[8];
-                load8<T>(res + off, r8);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r8[e];
-            }
-            if (p.act == CS_ACT_RELU) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else if (p.act == CS_ACT_SILU) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const int col = wn * (BN / 2) + j * 32 + l31;
+                        Cs[row * BN + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
-            }
-            if (msk) {
-                float k8[8];
-                load8<T>(msk + off, k8);
+        for (int it = 0; it < ITERS; ++it) {
+            const int hrow = it * (256 / CG) + tid / CG;
+            const int row = half * HROWS + hrow;
+            const long long m = m0 + row;
+            if (m < p.M && ook) {
+                float v[8];
+                const float4 c0 = *reinterpret_cast<const float4*>(Cs + hrow * BN + cg * 8);
+                const float4 c1 = *reinterpret_cast<const float4*>(Cs + hrow * BN + cg * 8 + 4);
+                v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+                v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+                long long dpix = m;
+                if (p.dst_step != 1) {
+                    const long long img = m / ((long long)p.DH * p.DW);
+                    const int rem = (int)(m - img * (long long)p.DH * p.DW);
+                    const int a = rem / p.DW;
+                    const int b = rem - a * p.DW;
+                    dpix = (img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox;
+                }
+                const long long off = dpix * p.NOUT + o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
-            }
-            store8<T>(dst + off, v);
-            if (p.slab) {
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                if (res) {
+                    float r8[8];
+                    load8<T>(res + off, r8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    // statistics are those of the STORED (rounded) values
-                    const float w = to_f32<T>(from_f32<T>(v[e]));
-                    s1[e] += w;
-                    s2[e] += w * w;
+                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                }
+                if (p.act == CS_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                } else if (p.act == CS_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+                }
+                if (msk) {
+                    float k8[8];
+                    load8<T>(msk + off, k8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
+                }
+                store8<T>(dst + off, v);
+                if (p.slab) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        // statistics are those of the STORED (rounded) values
+                        const float w = to_f32<T>(from_f32<T>(v[e]));
+                        s1[e] += w;
+                        s2[e] += w * w;
+                    }
                 }
             }
         }
@@ -576,9 +586,13 @@ int igemm_mode(const IgemmParams& p) {
 
 template <typename T, int BM, int BN>
 int launch_igemm(const IgemmParams& p, hipStream_t st) {
-    constexpr size_t stage_bytes = 2ull * (BM + BN) * 8 * 16;
-    constexpr size_t epi_bytes = (size_t)BM * BN * 4;
-    constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    constexpr size_t one_stage = (size_t)(BM + BN) * 8 * 16;
+    constexpr size_t epi_bytes = (size_t)BM * BN * 2;          // (BM/2) x BN fp32, two passes
+    constexpr size_t red_bytes = 256 * 16 * 4;                 // statistics fold
+    const int nk_host = (p.Qtot + 7) / 8;
+    size_t lds = (nk_host <= 1 ? 1 : 2) * one_stage;           // a single K-step needs a single stage
+    if (lds < epi_bytes) lds = epi_bytes;
+    if (lds < red_bytes) lds = red_bytes;
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.NOUT + BN - 1) / BN), 1);
     const unsigned long long src_bytes = (unsigned long long)p.src_pixels * p.SC * sizeof(T);
     const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.wrow_chunks * 16ull;
@@ -604,6 +618,8 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // Tile choice: wide-N tiles when there are enough output channels; shrink BM when the grid
 // would not fill the 256 CUs.  Returns BM*1000+BN.
 int igemm_tile(long long M, int NOUT) {
+    static const int forced = [] { const char* e = getenv("CELLSEG_TILE"); return e ? atoi(e) : 0; }();   // experiments only
+    if (forced) return (NOUT <= 64 && forced % 1000 == 128) ? forced - 64 : forced;
     const long long mt128 = (M + 127) / 128;
     if (NOUT > 64) {
         const long long blocks = mt128 * ((NOUT + 127) / 128);
