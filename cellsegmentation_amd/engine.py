@@ -320,6 +320,33 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
     t, aux = state.t, state.aux
     grads = dict(grad_feeds)
     gsum_cache = {}
+    # One zero-filled fp32 arena for every raw weight-gradient buffer and column-sum vector of this backward pass
+    # (a single fill kernel instead of ~2 per convolution).
+    need_w_units, arena_elems = set(), 0
+    pi_ = 0
+    for ui_, u_ in enumerate(plan.units):
+        n_ = len(u_.params())
+        if u_.kind == "conv" and any(param_needs[pi_:pi_ + n_]):
+            g_ = aux[ui_].geom
+            need_w_units.add(ui_)
+            arena_elems += g_.K * g_.R * g_.S * (64 if u_.grouped else g_.C)
+        if u_.kind == "conv" and aux[ui_] is not None:
+            arena_elems += aux[ui_].geom.C + 8
+        pi_ += n_
+    dev_ = next(iter(grad_feeds.values())).device if grad_feeds else None
+    arena = torch.zeros((arena_elems,), dtype=torch.float32, device=dev_) if (arena_elems and dev_ is not None) else None
+    arena_pos = [0]
+
+    def take(shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n8 = (n + 7) // 8 * 8
+        if arena is None or arena_pos[0] + n8 > arena.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=dev_)
+        v = arena[arena_pos[0]:arena_pos[0] + n].view(shape)
+        arena_pos[0] += n8
+        return v
     left = dict(plan.consumers)
     pgrads = [None] * len(plan.param_list)
     pindex = {}
@@ -375,7 +402,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum = K.colsum(dz)
                     if not a.train and u.res is not None and grads.get(u.res) is g:
                         gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
-                raw = torch.zeros((geom.K, geom.R, geom.S, 64 if u.grouped else geom.C), dtype=torch.float32, device=x.device)
+                raw = take((geom.K, geom.R, geom.S, 64 if u.grouped else geom.C))
                 K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
                 dw = torch.empty_like(conv.weight)
                 dbias = torch.empty_like(conv.bias) if want_b else None
@@ -406,7 +433,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 final = left[u.src] == 0
                 pending = grads.pop(u.src, None)
                 mask = x if (u.src in plan.relu_slots and final) else None
-                cs = torch.zeros((geom.C,), dtype=torch.float32, device=x.device) if final else None
+                cs = take((geom.C,)) if final else None
                 dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs, grouped=u.grouped)
                 grads[u.src] = dx
                 if final:
