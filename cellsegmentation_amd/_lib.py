@@ -30,6 +30,7 @@ _SIGNATURES = {
     "cs_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_nhwc_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_bn_fold": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, _P]),
+    "cs_stage_conv_bn": (c_int, [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "cs_weight_prep": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "cs_conv2d_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "cs_conv2d_stats_workspace": (c_size_t, [c_longlong, c_int]),

@@ -101,6 +101,44 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// ---- fused staging for an eval-mode Conv+BN: BN fold + both weight layouts in ONE launch.  Every thread recomputes
+// scale[k] = gamma[k]/sqrt(var[k]+eps) for its element (cheap), workgroup 0 also writes scale/shift/rstd.
+template <typename T>
+__global__ void stage_conv_bn_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                     const float* __restrict__ conv_bias, int K, int Cin, int R, int S, int Cp, int Kp,
+                                     T* __restrict__ w_khwc, T* __restrict__ w_chwk, float* __restrict__ scale,
+                                     float* __restrict__ shift, float* __restrict__ rstd) {
+    const int RS = R * S;
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+            float r = 0.f, sc = 0.f, sh = 0.f;
+            if (k < K) {
+                r = 1.0f / sqrtf(var[k] + eps);
+                sc = (gamma ? gamma[k] : 1.f) * r;
+                sh = (beta ? beta[k] : 0.f) + ((conv_bias ? conv_bias[k] : 0.f) - mean[k]) * sc;
+            }
+            scale[k] = sc; shift[k] = sh; rstd[k] = r;
+        }
+    }
+    const long long t1 = w_khwc ? (long long)Kp * RS * Cp : 0;
+    const long long t2 = w_chwk ? (long long)Cp * RS * Kp : 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < t1 + t2; idx += (long long)gridDim.x * blockDim.x) {
+        int k, c, rs;
+        const bool first = idx < t1;
+        if (first) {
+            c = (int)(idx % Cp); rs = (int)((idx / Cp) % RS); k = (int)(idx / ((long long)Cp * RS));
+        } else {
+            const long long j = idx - t1;
+            k = (int)(j % Kp); rs = (int)((j / Kp) % RS); c = (int)(j / ((long long)Kp * RS));
+        }
+        float v = 0.f;
+        if (k < K && c < Cin) v = w[((long long)k * Cin + c) * RS + rs] * ((gamma ? gamma[k] : 1.f) * (1.0f / sqrtf(var[k] + eps)));
+        if (first) w_khwc[idx] = from_f32<T>(v);
+        else w_chwk[idx - t1] = from_f32<T>(v);
+    }
+}
+
 // ---- grouped weights: fp32 [K][Cg][R][S] (x scale[k]) -> slab-dense T [K][R][S][64] and T [C][R][S][64]
 // (K == C, groups of Cg channels, 64-channel slabs; entries outside a channel's own group are zero)
 template <typename T>
@@ -369,6 +407,25 @@ extern "C" int cs_wgrad_finalize_grouped(const float* dw_slab, const float* w, c
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(wgrad_finalize_grouped_kernel, dim3(K), dim3(256), 0, st, dw_slab, w, scale, rstd, mean, gsum, Cg, R, S, dw, dgamma,
                        dbeta);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_stage_conv_bn(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                const float* conv_bias, int dtype, int K, int Cin, int R, int S, int Cp, int Kp, void* w_khwc,
+                                void* w_chwk, float* scale, float* shift, float* rstd, void* stream) {
+    CS_CHECK_ARG(w && mean && var && scale && shift && rstd && (w_khwc || w_chwk), "stage_conv_bn: NULL tensor");
+    CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "stage_conv_bn: bad extents");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (w_khwc ? (long long)Kp * R * S * Cp : 0) + (w_chwk ? (long long)Cp * R * S * Kp : 0);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(stage_conv_bn_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, gamma, beta, mean, var, eps,
+                           conv_bias, K, Cin, R, S, Cp, Kp, (float*)w_khwc, (float*)w_chwk, scale, shift, rstd);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(stage_conv_bn_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, gamma, beta, mean, var, eps,
+                           conv_bias, K, Cin, R, S, Cp, Kp, (bf16_t*)w_khwc, (bf16_t*)w_chwk, scale, shift, rstd);
+    else
+        CS_CHECK_ARG(false, "stage_conv_bn: bad dtype");
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -185,6 +185,12 @@ def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded):
     w = conv.weight.detach()
     bias = conv.bias.detach() if conv.bias is not None else None
     scale = shift = rstd = None
+    if folded and bn is not None and not u.grouped:
+        w_khwc, w_chwk, scale, shift, rstd = K.stage_conv_bn(w, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                             bn.eps, bias, dtype, Cp, Kp, want_bwd=need_bwd)
+        staged = SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd)
+        u._cache = (key, staged)
+        return staged
     if folded and bn is not None:
         scale, shift, rstd = K.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bias)
     else:

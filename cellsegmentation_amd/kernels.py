@@ -78,6 +78,17 @@ def bn_fold(gamma, beta, mean, var, eps, conv_bias=None):
     return out[0], out[1], out[2]
 
 
+def stage_conv_bn(w, gamma, beta, mean, var, eps, conv_bias, dtype, Cp, Kp, want_bwd=False):
+    """Fused BN fold + weight staging. Returns w_khwc, w_chwk, scale, shift, rstd (the last three [Kp])."""
+    K_, Cin, R, S = w.shape
+    w_khwc = torch.empty((Kp, R, S, Cp), dtype=dtype, device=w.device)
+    w_chwk = torch.empty((Cp, R, S, Kp), dtype=dtype, device=w.device) if want_bwd else None
+    vec = torch.empty((3, Kp), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().cs_stage_conv_bn(_p(w), _p(gamma), _p(beta), _p(mean), _p(var), eps, _p(conv_bias), _code(dtype), K_, Cin, R, S,
+                                            Cp, Kp, _p(w_khwc), _p(w_chwk), _p(vec[0]), _p(vec[1]), _p(vec[2]), _stream()), "stage_conv_bn")
+    return w_khwc, w_chwk, vec[0], vec[1], vec[2]
+
+
 def weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=False):
     K, Cin, R, S = w.shape
     w_khwc = torch.empty((Kp, R, S, Cp), dtype=dtype, device=w.device) if want_fwd else None

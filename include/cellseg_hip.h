@@ -87,6 +87,11 @@ int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const float* mean,
 int cs_weight_prep(const float* w, const float* scale, int dtype, int K, int Cin, int R, int S, int Cp, int Kp,
                    void* w_khwc, void* w_chwk, void* stream);
 
+/* cs_bn_fold + cs_weight_prep in one launch for an eval-mode Conv2d+BatchNorm2d (scale/shift/rstd are [Kp]). */
+int cs_stage_conv_bn(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                     const float* conv_bias, int dtype, int K, int Cin, int R, int S, int Cp, int Kp, void* w_khwc,
+                     void* w_chwk, float* scale, float* shift, float* rstd, void* stream);
+
 /* ---- convolution family (implicit GEMM on MFMA) ---------------------------------------------
  * forward: y = act( scale[k]*conv(x,w) + shift[k] + residual ), any of scale/shift/residual NULL.
  *   Fuses Conv2d+BatchNorm2d(eval)+ReLU(+residual add) of BasicBlock/Bottleneck.forward
