@@ -798,6 +798,7 @@ struct WgradParams {
     int slab;         // grouped: output-channel tile k0 (BM == 64) reads source channels [k0, k0+64)
     int SCc;          // C / chunk
     long long m_per_split;   // multiple of the K-step
+    long long slab_stride;   // elements between split-K slabs (KO*QE)
 };
 
 template <typename T, int BM, int BN, bool TR>
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const long long mbeg = (long long)blockIdx.z * p.m_per_split;
     long long mend = mbeg + p.m_per_split;
     if (mend > p.M) mend = p.M;
-    if (mbeg >= mend) return;
+    // (slices are non-empty by construction: nsplit = ceil(M / m_per_split); an empty one would still write zeros)
 
     const T* __restrict__ xs = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ gs = reinterpret_cast<const T*>(p.dy);
@@ -998,7 +999,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         __syncthreads();
     }
 
-    // ---- split-K combine: fp32 atomics, 32 consecutive q per half-wave (128-B segments) ----
+    // ---- split-K partials: slice z writes its tile into slab z with PLAIN stores (32 consecutive q per half-wave =
+    // 128-B segments).  fp32 atomics run at ~1.3 TB/s chip-wide and were the floor of this kernel (~50 us per launch);
+    // plain stores are ~5x faster, need no zero-fill, and the fold over slabs (cs_wgrad_finalize) is deterministic.
+    float* slab = p.dw + (long long)blockIdx.z * p.slab_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1007,44 +1011,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ko = k0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (ko < p.KO && qe < p.QE) atomicAdd(p.dw + (long long)ko * p.QE + qe, acc[i][j][r]);
+                if (ko < p.KO && qe < p.QE) slab[(long long)ko * p.QE + qe] = acc[i][j][r];
             }
         }
 }
 
-template <typename T, int BM, int BN, bool TR>
-int launch_wgrad(WgradParams p, hipStream_t st) {
-    const int tiles = cs_ceil_div(p.KO, BM) * cs_ceil_div(p.QE, BN);
-    // aim for ~4 workgroups per CU over the whole grid, at least 4 K-steps per slice
-    long long want = (1024 + tiles - 1) / tiles;
-    long long max_split = (p.M + 127) / 128;
+// number of split-K slices for KO x QE outputs over M pixels with a BM x 128 tile: ~768 workgroups (3 per CU),
+// at least 2 K-steps per slice
+int wgrad_splits(long long M, int KO, int QE, int BM) {
+    const int tiles = cs_ceil_div(KO, BM) * cs_ceil_div(QE, 128);
+    long long want = (768 + tiles - 1) / tiles;
+    const long long max_split = (M + 63) / 64;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
+    long long per = (M + want - 1) / want;
+    per = ((per + 31) / 32) * 32;
+    return (int)((M + per - 1) / per);
+}
+
+template <typename T, int BM, int BN, bool TR>
+int launch_wgrad(WgradParams p, hipStream_t st) {
     constexpr int BKP = 32;
     constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
-    long long per = (p.M + want - 1) / want;
+    const int nsplit = wgrad_splits(p.M, p.KO, p.QE, BM);
+    long long per = (p.M + nsplit - 1) / nsplit;
     per = ((per + BKP - 1) / BKP) * BKP;
-    const int nsplit = (int)((p.M + per - 1) / per);
     p.m_per_split = per;
+    p.slab_stride = (long long)p.KO * p.QE;
     constexpr size_t lds = 2ull * BKP * (BM + BN + 2 * PADE) * sizeof(T);
-    dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), nsplit);
-    if (lds > 65536) {
-        static bool raised = false;      // per template instantiation
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BM, BN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) {
-                cs_set_error_("wgrad: cannot raise the dynamic LDS limit");
-                return CS_ERR_LAUNCH;
-            }
-            raised = true;
-        }
-    }
+    dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), (unsigned)nsplit);
     hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
 
 }  // namespace
+
+extern "C" int cs_conv2d_wgrad_splits(const CsConvGeom* g, int grouped) {
+    if (!g) return 0;
+    const bool wide = g->K > 64 && !grouped;
+    const int cq = grouped ? 64 : g->C;
+    return wgrad_splits((long long)g->N * g->P * g->Q, g->K, g->R * g->S * cq, wide ? 128 : 64);
+}
 
 extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                                int use_tr_read, void* stream) {

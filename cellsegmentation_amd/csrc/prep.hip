@@ -172,7 +172,7 @@ __global__ void weight_prep_grouped_kernel(const float* __restrict__ w, const fl
 __global__ __launch_bounds__(256) void wgrad_finalize_grouped_kernel(const float* __restrict__ raw, const float* __restrict__ w,
                                                                      const float* scale, const float* rstd, const float* mean,
                                                                      const float* gsum, int Cg, int R, int S, float* __restrict__ dw,
-                                                                     float* dgamma, float* dbeta) {
+                                                                     float* dgamma, float* dbeta, int nsplit, long long slab_stride) {
     const int k = blockIdx.x;
     const int RS = R * S;
     const int per = Cg * RS;
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void wgrad_finalize_grouped_kernel(const float
     float dot = 0.f;
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
         const int c = j / RS, rs = j - c * RS;
-        const float r = raw[((long long)k * RS + rs) * 64 + base + c];
+        float r = 0.f;
+        for (int z = 0; z < nsplit; ++z) r += raw[z * slab_stride + ((long long)k * RS + rs) * 64 + base + c];
         const long long o = (long long)k * per + j;
         if (dgamma) dot += w[o] * r;
         dw[o] = sc * r;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
                                                              const float* scale, const float* rstd, const float* mean,
                                                              const float* gsum, int Cin, int R, int S, int Cp,
                                                              float* __restrict__ dw, float* dbias, float* dgamma,
-                                                             float* dbeta, int accumulate) {
+                                                             float* dbeta, int accumulate, int nsplit, long long slab_stride) {
     const int k = blockIdx.x;
     const int RS = R * S;
     const int per = Cin * RS;
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
         const int c = j / RS;
         const int rs = j - c * RS;
-        const float raw = dw_khwc[((long long)k * RS + rs) * Cp + c];
+        float raw = 0.f;
+        for (int z = 0; z < nsplit; ++z) raw += dw_khwc[z * slab_stride + ((long long)k * RS + rs) * Cp + c];   // fixed order: deterministic
         const long long o = (long long)k * per + j;
         if (dgamma) dot += w[o] * raw;
         const float val = sc * raw;
@@ -348,16 +350,17 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
     return CS_OK;
 }
 
-extern "C" int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, const float* rstd,
+extern "C" int cs_wgrad_finalize(const float* dw_khwc, int nsplit, int Kp, const float* w, const float* scale, const float* rstd,
                                  const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp, float* dw,
                                  float* dbias, float* dgamma, float* dbeta, int accumulate, void* stream) {
+    CS_CHECK_ARG(nsplit >= 1 && Kp >= K, "wgrad_finalize: bad nsplit / Kp");
     CS_CHECK_ARG(dw_khwc && dw, "wgrad_finalize: NULL tensor");
     CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin, "wgrad_finalize: bad extents");
     CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum), "wgrad_finalize: dgamma needs w, rstd, mean, gsum");
     CS_CHECK_ARG(!(dbeta || dbias) || gsum, "wgrad_finalize: dbeta/dbias need gsum");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(K), dim3(256), 0, st, dw_khwc, w, scale, rstd, mean, gsum, Cin, R, S, Cp, dw,
-                       dbias, dgamma, dbeta, accumulate);
+                       dbias, dgamma, dbeta, accumulate, nsplit, (long long)Kp * R * S * Cp);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
@@ -398,15 +401,16 @@ extern "C" int cs_weight_prep_grouped(const float* w, const float* scale, int dt
     return CS_OK;
 }
 
-extern "C" int cs_wgrad_finalize_grouped(const float* dw_slab, const float* w, const float* scale, const float* rstd, const float* mean,
-                                         const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma, float* dbeta,
-                                         void* stream) {
+extern "C" int cs_wgrad_finalize_grouped(const float* dw_slab, int nsplit, const float* w, const float* scale, const float* rstd,
+                                         const float* mean, const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma,
+                                         float* dbeta, void* stream) {
+    CS_CHECK_ARG(nsplit >= 1, "wgrad_finalize_grouped: bad nsplit");
     CS_CHECK_ARG(dw_slab && dw && K > 0 && Cg > 0 && 64 % Cg == 0, "wgrad_finalize_grouped: bad arguments");
     CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum), "wgrad_finalize_grouped: dgamma needs w, rstd, mean, gsum");
     CS_CHECK_ARG(!dbeta || gsum, "wgrad_finalize_grouped: dbeta needs gsum");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(wgrad_finalize_grouped_kernel, dim3(K), dim3(256), 0, st, dw_slab, w, scale, rstd, mean, gsum, Cg, R, S, dw, dgamma,
-                       dbeta);
+                       dbeta, nsplit, (long long)K * R * S * 64);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

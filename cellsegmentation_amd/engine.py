@@ -333,9 +333,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
     for ui_, u_ in enumerate(plan.units):
         n_ = len(u_.params())
         if u_.kind == "conv" and any(param_needs[pi_:pi_ + n_]):
-            g_ = aux[ui_].geom
             need_w_units.add(ui_)
-            arena_elems += g_.K * g_.R * g_.S * (64 if u_.grouped else g_.C)
         if u_.kind == "conv" and aux[ui_] is not None:
             arena_elems += aux[ui_].geom.C + 8
         pi_ += n_
@@ -408,7 +406,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum = K.colsum(dz)
                     if not a.train and u.res is not None and grads.get(u.res) is g:
                         gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
-                raw = take((geom.K, geom.R, geom.S, 64 if u.grouped else geom.C))
+                raw = K.new_wgrad_buffer(geom, x.device, u.grouped)
                 K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
                 dw = torch.empty_like(conv.weight)
                 dbias = torch.empty_like(conv.bias) if want_b else None

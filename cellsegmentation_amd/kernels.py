@@ -162,7 +162,7 @@ def weight_prep_grouped(w, scale, dtype, want_fwd=True, want_bwd=False):
 
 def wgrad_finalize_grouped(dw_slab, w, scale, rstd, mean, gsum, dw, dgamma=None, dbeta=None):
     K_, Cg, R, S = dw.shape
-    _lib.check(_lib.load().cs_wgrad_finalize_grouped(_p(dw_slab), _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K_, Cg, R, S, _p(dw),
+    _lib.check(_lib.load().cs_wgrad_finalize_grouped(_p(dw_slab), dw_slab.shape[0], _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K_, Cg, R, S, _p(dw),
                                                      _p(dgamma), _p(dbeta), _stream()), "wgrad_finalize_grouped")
 
 
@@ -193,8 +193,19 @@ def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False
     return dx
 
 
+def wgrad_splits(geom, grouped=False):
+    return _lib.load().cs_conv2d_wgrad_splits(ctypes.byref(geom), 1 if grouped else 0)
+
+
+def new_wgrad_buffer(geom, device, grouped=False):
+    """[nsplit, K, R, S, Cp|64] fp32 split-K partial slabs (no zero-fill needed)."""
+    return torch.empty((wgrad_splits(geom, grouped), geom.K, geom.R, geom.S, 64 if grouped else geom.C), dtype=torch.float32, device=device)
+
+
 def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
-    """dw_raw[K,R,S,Cp] fp32 (pre-zeroed) += wgrad (grouped: [K,R,S,64] slab-dense)."""
+    """dw_raw = new_wgrad_buffer(...): every slab is fully written by the kernel."""
+    if dw_raw.dim() != 5 or dw_raw.shape[0] != wgrad_splits(geom, grouped):
+        raise ValueError("conv_wgrad: dw_raw must come from new_wgrad_buffer(geom, ...)")
     lib = _lib.load()
     _mark_grouped(grouped)
     _lib.check(_timed("wgrad", geom, x.dtype, lambda: lib.cs_conv2d_wgrad(
@@ -203,9 +214,9 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
 
 
 def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False):
-    _, R, S, Cp = dw_raw.shape
+    nsplit, Kp, R, S, Cp = dw_raw.shape
     K = dw.shape[0]
-    _lib.check(_lib.load().cs_wgrad_finalize(_p(dw_raw), _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K, Cin, R, S, Cp,
+    _lib.check(_lib.load().cs_wgrad_finalize(_p(dw_raw), nsplit, Kp, _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K, Cin, R, S, Cp,
                                              _p(dw), _p(dbias), _p(dgamma), _p(dbeta), 1 if accumulate else 0, _stream()),
                "wgrad_finalize")
 

@@ -115,14 +115,16 @@ int cs_set_igemm_path(int path);
  *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */
 int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                     const void* mask, void* dx, float* colsum, void* workspace, void* stream);
-/* weight gradient, raw: dw_khwc[K][R][S][Cp] fp32 += sum over pixels dy (x) im2col(x).
- *   The caller zeroes dw_khwc first; split-K partial sums are combined with fp32 atomics. */
+/* weight gradient, raw split-K partials: dw_khwc[nsplit][K][R][S][Cp] fp32, slab z = sum over pixel slice z of
+ *   dy (x) im2col(x), written with plain stores (no zero-fill needed; nsplit = cs_conv2d_wgrad_splits(g, grouped));
+ *   cs_wgrad_finalize folds the slabs in a fixed order (bitwise reproducible). */
+int cs_conv2d_wgrad_splits(const CsConvGeom* g, int grouped);
 int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                     int use_tr_read, void* stream);
 /* dw[K][Cin][R][S] (torch layout, ACCUMULATED into when accumulate!=0) = scale[k]*dw_khwc[k][r][s][c];
  * dbias[k] = scale[k]*gsum[k] (conv bias); and, when dgamma/dbeta non-NULL, the eval-mode BatchNorm parameter gradients
  *   dbeta[k] = gsum[k];  dgamma[k] = rstd[k]*( sum_j w[k][j]*dw_raw[k][j] - mean[k]*gsum[k] ). */
-int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, const float* rstd,
+int cs_wgrad_finalize(const float* dw_khwc, int nsplit, int Kp, const float* w, const float* scale, const float* rstd,
                       const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp,
                       float* dw, float* dbias, float* dgamma, float* dbeta, int accumulate, void* stream);
 /* ---- grouped 3x3 convolution (ResNeXt, model/resnext.py:16-19,85: groups=32) in slab-dense form ------------
@@ -135,9 +137,9 @@ int cs_wgrad_finalize(const float* dw_khwc, const float* w, const float* scale, 
 int cs_weight_prep_grouped(const float* w, const float* scale, int dtype, int K, int Cg, int R, int S, void* w_khwc,
                            void* w_chwk, void* stream);
 int cs_conv2d_next_is_grouped(void);
-int cs_wgrad_finalize_grouped(const float* dw_slab, const float* w, const float* scale, const float* rstd, const float* mean,
-                              const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma, float* dbeta,
-                              void* stream);
+int cs_wgrad_finalize_grouped(const float* dw_slab, int nsplit, const float* w, const float* scale, const float* rstd,
+                              const float* mean, const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma,
+                              float* dbeta, void* stream);
 /* per-channel column sums: out[c] (+)= sum_m g[m][c]; fp32 out, zeroed by the caller. */
 int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream);
 

@@ -111,7 +111,8 @@ def test_conv_fwd_dgrad_wgrad(shape, dtype, dev, igemm_path):
     # ---------- wgrad (both LDS operand paths for bf16)
     ref_dw = torch.nn.grad.conv2d_weight(x, (Cout, Cin, R, R), dy, stride=s, padding=p)
     for use_tr in ([False, True] if dtype == torch.bfloat16 else [False]):
-        raw = torch.zeros((Kp, R, R, Cp), dtype=torch.float32, device=dev)
+        raw = K.new_wgrad_buffer(geom, dev)
+        raw.fill_(float("nan"))                      # every slab element must be overwritten by the kernel
         K.conv_wgrad(geom, xd, dyd, raw, use_tr_read=use_tr)
         dw = torch.empty((Cout, Cin, R, R), dtype=torch.float32, device=dev)
         gsum = K.colsum(dyd)
@@ -145,7 +146,7 @@ def test_bn_fold_and_finalize_bn_grads(dev):
     geom = K.make_geom(N, H, H, C, Kc, 3, 3, 1, 1)
     xd = _nhwc(x, torch.float32, dev)
     gd = _nhwc(g, torch.float32, dev)
-    raw = torch.zeros((Kc, 3, 3, C), dtype=torch.float32, device=dev)
+    raw = K.new_wgrad_buffer(geom, dev)
     K.conv_wgrad(geom, xd, gd, raw)
     gsum = K.colsum(gd)
     dw = torch.empty((Kc, C, 3, 3), device=dev)
@@ -174,7 +175,7 @@ def test_grouped_conv_slab_dense(cfg, dtype, dev, igemm_path):
     wk, wc = K.weight_prep_grouped(w.detach().to(dev), None, dtype, True, True)
     yd = K.conv_fwd(geom, xd, wk, grouped=True)
     dxd = K.conv_dgrad(geom, dyd, wc, grouped=True)
-    raw = torch.zeros((C, 3, 3, 64), dtype=torch.float32, device=dev)
+    raw = K.new_wgrad_buffer(geom, dev, grouped=True)
     K.conv_wgrad(geom, xd, dyd, raw, grouped=True)
     dw = torch.empty_like(w.detach()).to(dev)
     K.wgrad_finalize_grouped(raw, None, None, None, None, None, dw)

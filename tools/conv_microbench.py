@@ -36,7 +36,7 @@ def main():
         w = torch.randn((Kc, C, R, R), device=dev) * (1.0 / (C * R * R) ** 0.5)
         wk, wc = K.weight_prep(w, None, dt, C, Kc, True, True)
         dy = torch.randn((N, g.P, g.Q, Kc), device=dev).to(dt)
-        raw = torch.zeros((Kc, R, R, C), dtype=torch.float32, device=dev)
+        raw = K.new_wgrad_buffer(g, dev)
         shift = torch.zeros((Kc,), device=dev)
         flops = 2.0 * N * g.P * g.Q * Kc * C * R * R
         res = {}
