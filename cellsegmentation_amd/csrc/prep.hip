@@ -167,76 +167,52 @@ __global__ void weight_prep_grouped_kernel(const float* __restrict__ w, const fl
     }
 }
 
-// dw[k][cg][r][s] = scale[k] * raw[k][r][s][base(k)+cg] with base(k) = ((k%64)/Cg)*Cg; BN-eval parameter grads as in
-// wgrad_finalize_kernel.  One workgroup per k.
-__global__ __launch_bounds__(256) void wgrad_finalize_grouped_kernel(const float* __restrict__ raw, const float* __restrict__ w,
-                                                                     const float* scale, const float* rstd, const float* mean,
-                                                                     const float* gsum, int Cg, int R, int S, float* __restrict__ dw,
-                                                                     float* dgamma, float* dbeta, int nsplit, long long slab_stride) {
-    const int k = blockIdx.x;
-    const int RS = R * S;
-    const int per = Cg * RS;
-    const int base = ((k % 64) / Cg) * Cg;
-    const float sc = scale ? scale[k] : 1.f;
-    float dot = 0.f;
-    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+// ---- wgrad finalize.  Pass A: grid (ceil(Cin*R*S / 256), K): each thread folds the nsplit partial slabs of ONE weight
+// (fixed order -> bitwise reproducible; consecutive threads read consecutive slab addresses), writes dw in torch layout and
+// contributes w*dw_raw to a per-channel dot product (one atomic per workgroup).  Pass B (K threads): BN-eval parameter
+// gradients / conv-bias gradient from the dot products and the column sums.
+__global__ __launch_bounds__(256) void wgrad_finalize_a_kernel(const float* __restrict__ dw_khwc, const float* __restrict__ w,
+                                                               const float* scale, int Cin, int RS, int Cp, int Cg_slab,
+                                                               float* __restrict__ dw, float* __restrict__ dot, int accumulate,
+                                                               int nsplit, long long slab_stride) {
+    // Cg_slab == 0: dense weights, raw row layout [rs][Cp];  Cg_slab > 0: grouped slab-dense, raw row [rs][64], Cin == Cg
+    const int k = blockIdx.y;
+    const int per = Cin * RS;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.f;
+    if (j < per) {
         const int c = j / RS, rs = j - c * RS;
-        float r = 0.f;
-        for (int z = 0; z < nsplit; ++z) r += raw[z * slab_stride + ((long long)k * RS + rs) * 64 + base + c];
+        const long long src = Cg_slab ? ((long long)k * RS + rs) * 64 + ((k % 64) / Cg_slab) * Cg_slab + c
+                                      : ((long long)k * RS + rs) * Cp + c;
+        float raw = 0.f;
+        for (int z = 0; z < nsplit; ++z) raw += dw_khwc[z * slab_stride + src];
         const long long o = (long long)k * per + j;
-        if (dgamma) dot += w[o] * r;
-        dw[o] = sc * r;
+        if (dot) contrib = w[o] * raw;
+        const float val = (scale ? scale[k] : 1.f) * raw;
+        dw[o] = accumulate ? dw[o] + val : val;
     }
-    if (dgamma || dbeta) {
+    if (dot) {
         __shared__ float red[4];
-        dot = wave_sum(dot);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+        contrib = wave_sum(contrib);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const float tot = red[0] + red[1] + red[2] + red[3];
-            const float gs = gsum ? gsum[k] : 0.f;
-            if (dgamma) dgamma[k] = rstd[k] * (tot - mean[k] * gs);
-            if (dbeta) dbeta[k] = gs;
-        }
+        if (threadIdx.x == 0) atomicAdd(dot + k, red[0] + red[1] + red[2] + red[3]);
     }
 }
 
-// ---- wgrad finalize: one workgroup per output channel k --------------------------------------
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ dw_khwc, const float* __restrict__ w,
-                                                             const float* scale, const float* rstd, const float* mean,
-                                                             const float* gsum, int Cin, int R, int S, int Cp,
-                                                             float* __restrict__ dw, float* dbias, float* dgamma,
-                                                             float* dbeta, int accumulate, int nsplit, long long slab_stride) {
-    const int k = blockIdx.x;
-    const int RS = R * S;
-    const int per = Cin * RS;
-    const float sc = scale ? scale[k] : 1.f;
-    float dot = 0.f;
-    for (int j = threadIdx.x; j < per; j += blockDim.x) {
-        const int c = j / RS;
-        const int rs = j - c * RS;
-        float raw = 0.f;
-        for (int z = 0; z < nsplit; ++z) raw += dw_khwc[z * slab_stride + ((long long)k * RS + rs) * Cp + c];   // fixed order: deterministic
-        const long long o = (long long)k * per + j;
-        if (dgamma) dot += w[o] * raw;
-        const float val = sc * raw;
-        dw[o] = accumulate ? dw[o] + val : val;
+__global__ void wgrad_finalize_b_kernel(const float* __restrict__ dot, const float* scale, const float* rstd, const float* mean,
+                                        const float* gsum, float* dbias, float* dgamma, float* dbeta, int K, int accumulate) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float gs = gsum ? gsum[k] : 0.f;
+    if (dgamma) {
+        const float v = rstd[k] * (dot[k] - mean[k] * gs);
+        dgamma[k] = accumulate ? dgamma[k] + v : v;
     }
-    if (dgamma || dbeta || dbias) {
-        __shared__ float red[4];
-        dot = wave_sum(dot);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float tot = red[0] + red[1] + red[2] + red[3];
-            const float gs = gsum ? gsum[k] : 0.f;
-            if (dgamma) {
-                const float v = rstd[k] * (tot - mean[k] * gs);
-                dgamma[k] = accumulate ? dgamma[k] + v : v;
-            }
-            if (dbeta) dbeta[k] = accumulate ? dbeta[k] + gs : gs;
-            if (dbias) dbias[k] = accumulate ? dbias[k] + sc * gs : sc * gs;
-        }
+    if (dbeta) dbeta[k] = accumulate ? dbeta[k] + gs : gs;
+    if (dbias) {
+        const float v = (scale ? scale[k] : 1.f) * gs;
+        dbias[k] = accumulate ? dbias[k] + v : v;
     }
 }
 
@@ -350,19 +326,36 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
     return CS_OK;
 }
 
+static int finalize_common(const float* raw, int nsplit, long long slab_stride, const float* w, const float* scale, const float* rstd,
+                           const float* mean, const float* gsum, int K, int Cin, int RS, int Cp, int Cg_slab, float* dw, float* dbias,
+                           float* dgamma, float* dbeta, float* dot_ws, int accumulate, hipStream_t st) {
+    float* dot = dgamma ? dot_ws : nullptr;
+    if (dot && hipMemsetAsync(dot, 0, sizeof(float) * K, st) != hipSuccess) {
+        cs_set_error_("wgrad_finalize: memset failed");
+        return CS_ERR_LAUNCH;
+    }
+    const int per = Cin * RS;
+    hipLaunchKernelGGL(wgrad_finalize_a_kernel, dim3((per + 255) / 256, K), dim3(256), 0, st, raw, w, scale, Cin, RS, Cp, Cg_slab, dw, dot,
+                       accumulate, nsplit, slab_stride);
+    CS_LAUNCH_CHECK();
+    if (dgamma || dbeta || dbias) {
+        hipLaunchKernelGGL(wgrad_finalize_b_kernel, dim3((K + 255) / 256), dim3(256), 0, st, dot, scale, rstd, mean, gsum, dbias, dgamma,
+                           dbeta, K, accumulate);
+        CS_LAUNCH_CHECK();
+    }
+    return CS_OK;
+}
+
 extern "C" int cs_wgrad_finalize(const float* dw_khwc, int nsplit, int Kp, const float* w, const float* scale, const float* rstd,
                                  const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp, float* dw,
-                                 float* dbias, float* dgamma, float* dbeta, int accumulate, void* stream) {
+                                 float* dbias, float* dgamma, float* dbeta, float* dot_ws, int accumulate, void* stream) {
     CS_CHECK_ARG(nsplit >= 1 && Kp >= K, "wgrad_finalize: bad nsplit / Kp");
     CS_CHECK_ARG(dw_khwc && dw, "wgrad_finalize: NULL tensor");
     CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin, "wgrad_finalize: bad extents");
-    CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum), "wgrad_finalize: dgamma needs w, rstd, mean, gsum");
+    CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum && dot_ws), "wgrad_finalize: dgamma needs w, rstd, mean, gsum, dot_ws[K]");
     CS_CHECK_ARG(!(dbeta || dbias) || gsum, "wgrad_finalize: dbeta/dbias need gsum");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(K), dim3(256), 0, st, dw_khwc, w, scale, rstd, mean, gsum, Cin, R, S, Cp, dw,
-                       dbias, dgamma, dbeta, accumulate, nsplit, (long long)Kp * R * S * Cp);
-    CS_LAUNCH_CHECK();
-    return CS_OK;
+    return finalize_common(dw_khwc, nsplit, (long long)Kp * R * S * Cp, w, scale, rstd, mean, gsum, K, Cin, R * S, Cp, 0, dw, dbias, dgamma,
+                           dbeta, dot_ws, accumulate, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream) {
@@ -403,33 +396,11 @@ extern "C" int cs_weight_prep_grouped(const float* w, const float* scale, int dt
 
 extern "C" int cs_wgrad_finalize_grouped(const float* dw_slab, int nsplit, const float* w, const float* scale, const float* rstd,
                                          const float* mean, const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma,
-                                         float* dbeta, void* stream) {
+                                         float* dbeta, float* dot_ws, void* stream) {
     CS_CHECK_ARG(nsplit >= 1, "wgrad_finalize_grouped: bad nsplit");
     CS_CHECK_ARG(dw_slab && dw && K > 0 && Cg > 0 && 64 % Cg == 0, "wgrad_finalize_grouped: bad arguments");
-    CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum), "wgrad_finalize_grouped: dgamma needs w, rstd, mean, gsum");
+    CS_CHECK_ARG(!dgamma || (w && rstd && mean && gsum && dot_ws), "wgrad_finalize_grouped: dgamma needs w, rstd, mean, gsum, dot_ws[K]");
     CS_CHECK_ARG(!dbeta || gsum, "wgrad_finalize_grouped: dbeta needs gsum");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(wgrad_finalize_grouped_kernel, dim3(K), dim3(256), 0, st, dw_slab, w, scale, rstd, mean, gsum, Cg, R, S, dw, dgamma,
-                       dbeta, nsplit, (long long)K * R * S * 64);
-    CS_LAUNCH_CHECK();
-    return CS_OK;
-}
-
-extern "C" int cs_stage_conv_bn(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                                const float* conv_bias, int dtype, int K, int Cin, int R, int S, int Cp, int Kp, void* w_khwc,
-                                void* w_chwk, float* scale, float* shift, float* rstd, void* stream) {
-    CS_CHECK_ARG(w && mean && var && scale && shift && rstd && (w_khwc || w_chwk), "stage_conv_bn: NULL tensor");
-    CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "stage_conv_bn: bad extents");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long long total = (w_khwc ? (long long)Kp * R * S * Cp : 0) + (w_chwk ? (long long)Cp * R * S * Kp : 0);
-    if (dtype == CS_F32)
-        hipLaunchKernelGGL(stage_conv_bn_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, gamma, beta, mean, var, eps,
-                           conv_bias, K, Cin, R, S, Cp, Kp, (float*)w_khwc, (float*)w_chwk, scale, shift, rstd);
-    else if (dtype == CS_BF16)
-        hipLaunchKernelGGL(stage_conv_bn_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, gamma, beta, mean, var, eps,
-                           conv_bias, K, Cin, R, S, Cp, Kp, (bf16_t*)w_khwc, (bf16_t*)w_chwk, scale, shift, rstd);
-    else
-        CS_CHECK_ARG(false, "stage_conv_bn: bad dtype");
-    CS_LAUNCH_CHECK();
-    return CS_OK;
+    return finalize_common(dw_slab, nsplit, (long long)K * R * S * 64, w, scale, rstd, mean, gsum, K, Cg, R * S, 64, Cg, dw, nullptr, dgamma,
+                           dbeta, dot_ws, 0, reinterpret_cast<hipStream_t>(stream));
 }
