@@ -404,3 +404,22 @@ extern "C" int cs_wgrad_finalize_grouped(const float* dw_slab, int nsplit, const
     return finalize_common(dw_slab, nsplit, (long long)K * R * S * 64, w, scale, rstd, mean, gsum, K, Cg, R * S, 64, Cg, dw, nullptr, dgamma,
                            dbeta, dot_ws, 0, reinterpret_cast<hipStream_t>(stream));
 }
+
+extern "C" int cs_stage_conv_bn(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                const float* conv_bias, int dtype, int K, int Cin, int R, int S, int Cp, int Kp, void* w_khwc,
+                                void* w_chwk, float* scale, float* shift, float* rstd, void* stream) {
+    CS_CHECK_ARG(w && mean && var && scale && shift && rstd && (w_khwc || w_chwk), "stage_conv_bn: NULL tensor");
+    CS_CHECK_ARG(K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "stage_conv_bn: bad extents");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (w_khwc ? (long long)Kp * R * S * Cp : 0) + (w_chwk ? (long long)Cp * R * S * Kp : 0);
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(stage_conv_bn_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, gamma, beta, mean, var, eps,
+                           conv_bias, K, Cin, R, S, Cp, Kp, (float*)w_khwc, (float*)w_chwk, scale, shift, rstd);
+    else if (dtype == CS_BF16)
+        hipLaunchKernelGGL(stage_conv_bn_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, w, gamma, beta, mean, var, eps,
+                           conv_bias, K, Cin, R, S, Cp, Kp, (bf16_t*)w_khwc, (bf16_t*)w_chwk, scale, shift, rstd);
+    else
+        CS_CHECK_ARG(false, "stage_conv_bn: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
