@@ -1016,11 +1016,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         }
 }
 
-// number of split-K slices for KO x QE outputs over M pixels with a BM x 128 tile: ~768 workgroups (3 per CU),
-// at least 2 K-steps per slice
+// number of split-K slices for KO x QE outputs over M pixels with a BM x 128 tile: ~512 workgroups (2 per CU);
+// every slice costs one extra write + read of the whole dW in fp32, so no more than needed to fill the chip
 int wgrad_splits(long long M, int KO, int QE, int BM) {
     const int tiles = cs_ceil_div(KO, BM) * cs_ceil_div(QE, 128);
-    long long want = (768 + tiles - 1) / tiles;
+    long long want = (512 + tiles - 1) / tiles;
     const long long max_split = (M + 63) / 64;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;

@@ -178,10 +178,13 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_kernel(const float* __re
     // Cg_slab == 0: dense weights, raw row layout [rs][Cp];  Cg_slab > 0: grouped slab-dense, raw row [rs][64], Cin == Cg
     const int k = blockIdx.y;
     const int per = Cin * RS;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    // threads walk the SLAB's own [rs][c] order: coalesced reads of the nsplit partials (the bulk of the traffic);
+    // the single write per weight lands RS-strided in torch's [c][rs] order
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float contrib = 0.f;
-    if (j < per) {
-        const int c = j / RS, rs = j - c * RS;
+    if (i < per) {
+        const int rs = i / Cin, c = i - rs * Cin;
+        const int j = c * RS + rs;
         const long long src = Cg_slab ? ((long long)k * RS + rs) * 64 + ((k % 64) / Cg_slab) * Cg_slab + c
                                       : ((long long)k * RS + rs) * Cp + c;
         float raw = 0.f;
@@ -329,11 +332,7 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
 static int finalize_common(const float* raw, int nsplit, long long slab_stride, const float* w, const float* scale, const float* rstd,
                            const float* mean, const float* gsum, int K, int Cin, int RS, int Cp, int Cg_slab, float* dw, float* dbias,
                            float* dgamma, float* dbeta, float* dot_ws, int accumulate, hipStream_t st) {
-    float* dot = dgamma ? dot_ws : nullptr;
-    if (dot && hipMemsetAsync(dot, 0, sizeof(float) * K, st) != hipSuccess) {
-        cs_set_error_("wgrad_finalize: memset failed");
-        return CS_ERR_LAUNCH;
-    }
+    float* dot = dgamma ? dot_ws : nullptr;      // zeroed by the caller
     const int per = Cin * RS;
     hipLaunchKernelGGL(wgrad_finalize_a_kernel, dim3((per + 255) / 256, K), dim3(256), 0, st, raw, w, scale, Cin, RS, Cp, Cg_slab, dw, dot,
                        accumulate, nsplit, slab_stride);

@@ -335,7 +335,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         if u_.kind == "conv" and any(param_needs[pi_:pi_ + n_]):
             need_w_units.add(ui_)
         if u_.kind == "conv" and aux[ui_] is not None:
-            arena_elems += aux[ui_].geom.C + 8
+            arena_elems += aux[ui_].geom.C + aux[ui_].geom.K + 16
         pi_ += n_
     dev_ = next(iter(grad_feeds.values())).device if grad_feeds else None
     arena = torch.zeros((arena_elems,), dtype=torch.float32, device=dev_) if (arena_elems and dev_ is not None) else None
@@ -414,14 +414,15 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 if want_bn and not a.train:
                     dgb = torch.empty((2, Kc), dtype=torch.float32, device=x.device)
                     dgamma, dbeta = dgb[0], dgb[1]
+                dot = take((Kc,)) if dgamma is not None else None
                 if u.grouped:
                     K.wgrad_finalize_grouped(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
                                              None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, dw,
-                                             dgamma=dgamma, dbeta=dbeta)
+                                             dgamma=dgamma, dbeta=dbeta, dot=dot)
                 else:
                     K.wgrad_finalize(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
                                      None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, Cin, dw,
-                                     dbias=dbias, dgamma=dgamma, dbeta=dbeta)
+                                     dbias=dbias, dgamma=dgamma, dbeta=dbeta, dot=dot)
                 if want_w:
                     pgrads[pindex[(ui, "weight")]] = dw
                 if want_b:

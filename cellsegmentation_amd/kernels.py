@@ -160,9 +160,10 @@ def weight_prep_grouped(w, scale, dtype, want_fwd=True, want_bwd=False):
     return w_khwc, w_chwk
 
 
-def wgrad_finalize_grouped(dw_slab, w, scale, rstd, mean, gsum, dw, dgamma=None, dbeta=None):
+def wgrad_finalize_grouped(dw_slab, w, scale, rstd, mean, gsum, dw, dgamma=None, dbeta=None, dot=None):
     K_, Cg, R, S = dw.shape
-    dot = torch.empty((K_,), dtype=torch.float32, device=dw.device) if dgamma is not None else None
+    if dgamma is not None and dot is None:
+        dot = torch.zeros((K_,), dtype=torch.float32, device=dw.device)
     _lib.check(_lib.load().cs_wgrad_finalize_grouped(_p(dw_slab), dw_slab.shape[0], _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K_, Cg, R, S, _p(dw),
                                                      _p(dgamma), _p(dbeta), _p(dot), _stream()), "wgrad_finalize_grouped")
 
@@ -214,10 +215,12 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
     return dw_raw
 
 
-def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False):
+def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False, dot=None):
+    """dot: zeroed fp32 [K] scratch (allocated here when omitted)."""
     nsplit, Kp, R, S, Cp = dw_raw.shape
     K = dw.shape[0]
-    dot = torch.empty((K,), dtype=torch.float32, device=dw.device) if dgamma is not None else None
+    if dgamma is not None and dot is None:
+        dot = torch.zeros((K,), dtype=torch.float32, device=dw.device)
     _lib.check(_lib.load().cs_wgrad_finalize(_p(dw_raw), nsplit, Kp, _p(w), _p(scale), _p(rstd), _p(mean), _p(gsum), K, Cin, R, S, Cp,
                                              _p(dw), _p(dbias), _p(dgamma), _p(dbeta), _p(dot), 1 if accumulate else 0, _stream()),
                "wgrad_finalize")

@@ -126,7 +126,7 @@ int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* d
  *   dbeta[k] = gsum[k];  dgamma[k] = rstd[k]*( sum_j w[k][j]*dw_raw[k][j] - mean[k]*gsum[k] ). */
 int cs_wgrad_finalize(const float* dw_khwc, int nsplit, int Kp, const float* w, const float* scale, const float* rstd,
                       const float* mean, const float* gsum, int K, int Cin, int R, int S, int Cp,
-                      float* dw, float* dbias, float* dgamma, float* dbeta, float* dot_ws /* fp32 [K] scratch, needed with dgamma */,
+                      float* dw, float* dbias, float* dgamma, float* dbeta, float* dot_ws /* fp32 [K] scratch ZEROED by the caller, needed with dgamma */,
                       int accumulate, void* stream);
 /* ---- grouped 3x3 convolution (ResNeXt, model/resnext.py:16-19,85: groups=32) in slab-dense form ------------
  * C == K, C % 64 == 0, Cg = C/groups divides 64.  Each 64-channel destination tile contracts only over its
