@@ -48,9 +48,27 @@ def build_model(dev, dtype):
     return m
 
 
+PEAK_HBM_GBS = 8000.0           # HBM3E, MI355X_MICROARCH.md "Chip-level parameters" (spec; ~6300 measured achievable)
+MACHINE_BALANCE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)     # FLOP per byte where the two roofs meet (~312)
+
+
 def conv_flops(g):
+    """Algorithmic FLOPs of one conv-family launch: 2*N*P*Q*K*C*R*S with the TRUE channel counts (stem C=3, not the padded 8)."""
     c_true = 3 if (g["R"] == 7 and g["C"] == 8) else g["C"]
     return 2.0 * g["N"] * g["P"] * g["Q"] * g["K"] * c_true * g["R"] * g["S"]
+
+
+def conv_bytes(kind, g, es):
+    """Algorithmic HBM bytes of one launch: every operand tensor once (activations in the storage dtype, weights once,
+    wgrad output in fp32), plus the destination-shaped tensors the fused epilogue reads (residual / add / mask)."""
+    x = g["N"] * g["H"] * g["W"] * g["C"] * es
+    y = g["N"] * g["P"] * g["Q"] * g["K"] * es
+    w = g["K"] * g["R"] * g["S"] * g["C"]
+    if kind == "fwd":
+        return x + y + w * es + g["extra"] * y
+    if kind == "dgrad":
+        return y + x + w * es + g["extra"] * x
+    return x + y + w * 4
 
 
 def kernel_name(kind, g, dtype):
@@ -71,30 +89,46 @@ def kernel_name(kind, g, dtype):
 
 
 def roofline_from(records, steps, dtype):
+    """Per-launch HIP-event times -> roofline of the dominant kernel instantiation (largest share of conv time).
+    Its bound is decided by its aggregate arithmetic intensity against the machine balance: HBM-bound kernels are priced in
+    algorithmic GB/s against the 8 TB/s spec, MFMA-bound ones in TFLOP/s against the dense bf16 peak."""
+    es = 2 if dtype == torch.bfloat16 else 4
     per_kernel, per_family = {}, {}
     for kind, g, dt, ms in records:
         name = kernel_name(kind, g, dt)
         fam = f"{g['R']}x{g['S']}/{kind}"
-        fl = conv_flops(g)
+        fl, by = conv_flops(g), conv_bytes(kind, g, es)
         for table, key in ((per_kernel, name), (per_family, fam)):
-            e = table.setdefault(key, [0.0, 0.0, 0])
-            e[0] += fl; e[1] += ms; e[2] += 1
+            e = table.setdefault(key, [0.0, 0.0, 0, 0.0])
+            e[0] += fl; e[1] += ms; e[2] += 1; e[3] += by
     if not per_kernel:
         return None
+    peak_tf = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    balance = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+
+    def row(v, per_step=False):
+        out = {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "gbps": round(v[3] / (v[1] * 1e-3) / 1e9, 0),
+               "flop_per_byte": round(v[0] / v[3], 1)}
+        if per_step:
+            out.update(ms_per_step=round(v[1] / steps, 3), launches_per_step=v[2] // steps)
+        else:
+            out.update(avg_ms=round(v[1] / v[2], 4), launches=v[2])
+        return out
+
     dom = max(per_kernel, key=lambda k: per_kernel[k][1])
-    fl, ms, n = per_kernel[dom]
-    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-    achieved = fl / (ms * 1e-3) / 1e12
-    fams = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1] / steps, 3), "launches_per_step": v[2] // steps}
-            for k, v in sorted(per_family.items())}
-    kerns = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "avg_ms": round(v[1] / v[2], 4), "launches": v[2]}
-             for k, v in sorted(per_kernel.items())}
+    fl, ms, n, by = per_kernel[dom]
+    if fl / by < balance:
+        achieved, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+    else:
+        achieved, peak, unit, bound = fl / (ms * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
     three = [v for k, v in per_family.items() if k.startswith("3x3")]
     t3 = sum(v[0] for v in three) / (sum(v[1] for v in three) * 1e-3) / 1e12 if three else None
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+    return {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
             "traffic": None, "kernel": dom, "avg_launch_ms": round(ms / n, 4), "launches": n,
-            "conv3x3_family_tflops": round(t3, 2) if t3 else None, "conv3x3_family_frac": round(t3 / peak, 4) if t3 else None,
-            "by_kernel": kerns, "by_family": fams}
+            "algorithmic_per_launch": {"gflop": round(fl / n / 1e9, 3), "mbytes": round(by / n / 1e6, 2), "flop_per_byte": round(fl / by, 1)},
+            "conv3x3_family_tflops": round(t3, 2) if t3 else None, "conv3x3_family_frac_of_mfma_peak": round(t3 / peak_tf, 4) if t3 else None,
+            "by_kernel": {k: row(v) for k, v in sorted(per_kernel.items())},
+            "by_family": {k: row(v, True) for k, v in sorted(per_family.items())}}
 
 
 def cpu_baseline(sample_tiles=8, steps=2):

@@ -123,14 +123,17 @@ class LaunchTimer:
 _timer = None
 
 
-def _timed(kind, geom, dtype, fn):
+def _timed(kind, geom, dtype, fn, extra_tensors=0):
+    """extra_tensors: how many destination-shaped tensors the epilogue also reads (residual / add / mask)."""
     if _timer is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     rc = fn()
     e.record()
-    _timer.records.append((kind, {f: getattr(geom, f) for f, _ in geom._fields_}, dtype, s, e))
+    g = {f: getattr(geom, f) for f, _ in geom._fields_}
+    g["extra"] = extra_tensors
+    _timer.records.append((kind, g, dtype, s, e))
     return rc
 
 
@@ -180,7 +183,7 @@ def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_
     ws = _stats_ws(geom.N * geom.P * geom.Q, geom.K, x.device) if stats is not None else None
     _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd(
         ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(stats), _p(ws),
-        _stream())), "conv2d_fwd")
+        _stream()), extra_tensors=int(residual is not None)), "conv2d_fwd")
     return y
 
 
@@ -190,8 +193,8 @@ def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False
     _mark_grouped(grouped)
     ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if colsum is not None else None
     _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
-        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _p(ws), _stream())),
-        "conv2d_dgrad")
+        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _p(ws), _stream()),
+        extra_tensors=int(add is not None) + int(mask is not None)), "conv2d_dgrad")
     return dx
 
 
