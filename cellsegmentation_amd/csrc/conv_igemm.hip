@@ -76,7 +76,7 @@ template <> struct Mma<float> {
 
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* smem_raw,
-                                               long long m0, int n0) {
+                                               long long m0, int n0, long long slab_row) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { t1[e] += red[r * 16 + e]; t2[e] += red[r * 16 + 8 + e]; }
             }
-            float* row = p.slab + (long long)blockIdx.x * 2 * p.NOUT;
+            float* row = p.slab + slab_row * 2 * p.NOUT;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { row[o + e] = t1[e]; row[p.NOUT + o + e] = t2[e]; }
         }
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0);
+    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, blockIdx.x);
 }
 
 
@@ -549,7 +549,110 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
         }
     }
     __syncthreads();
-    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0);
+    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, blockIdx.x);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for the HBM-bound pure-GEMM convolutions with a short contraction (1x1, C_in <= 128):
+// a PERSISTENT workgroup owns one destination-channel tile, keeps its weights resident in LDS, and walks
+// pixel tiles with the NEXT tile's LDS-DMA always in flight while the current tile is multiplied and
+// its epilogue (residual/mask loads, stores) drains -- the one-shot kernel had a single short burst
+// of loads per workgroup and then nothing outstanding (2.6 TB/s algorithmic); this keeps the memory
+// system busy.  LDS: [B: NK stages][A: 2 x NK stages][epilogue staging (BM/2 x BN fp32)].
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int NK>
+__global__ __launch_bounds__(256) void igemm_stream_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes, int n_mtiles) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int B_BYTES = NK * BN * 128;
+    constexpr int A_BYTES = NK * BM * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* Bs_base = smem_raw;
+    unsigned char* As_base = smem_raw + B_BYTES;
+    unsigned char* epi = As_base + 2 * A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, wgt_bytes, 0x00020000);
+    const int lr = tid >> 3;
+    const int lc = (tid & 7) ^ ((lr >> 1) & 7);
+    const unsigned wrow_bytes = (unsigned)p.wrow_chunks * 16u;
+    const unsigned row_bytes = (unsigned)p.SC * ES;
+
+    // weights: once per workgroup
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int q = ks * 8 + lc;
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int o = n0 + lr + 32 * j;
+            const unsigned vb = (o < p.NOUT && q < p.Qtot) ? (unsigned)o * wrow_bytes + (unsigned)q * 16u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs_base + ks * BN * 128 + (8 * wave + 32 * j) * 128),
+                                                     16, (int)vb, 0, 0, 0);
+        }
+    }
+    auto issue_a = [&](int tile, int buf) {
+        const long long m0 = (long long)tile * BM;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int q = ks * 8 + lc;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const long long m = m0 + lr + 32 * i;
+                const unsigned va = (m < p.M && q < p.Qtot) ? (unsigned)(m * row_bytes) + (unsigned)q * 16u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsrc_a, (__attribute__((address_space(3))) void*)(As_base + buf * A_BYTES + ks * BM * 128 + (8 * wave + 32 * i) * 128), 16,
+                    (int)va, 0, 0, 0);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_mtiles) issue_a(tile, 0);
+    for (int it = 0; tile < n_mtiles; tile += gridDim.x, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < n_mtiles) issue_a(nxt, (it + 1) & 1);
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const uint4* As = reinterpret_cast<const uint4*>(As_base + (it & 1) * A_BYTES + ks * BM * 128);
+            const uint4* Bs = reinterpret_cast<const uint4*>(Bs_base + ks * BN * 128);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c = 2 * kk + hh;
+                uint4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[swz(wm * (BM / 2) + i * 32 + l31, c)];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[swz(wn * (BN / 2) + j * 32 + l31, c)];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+            }
+        }
+        igemm_epilogue<T, BM, BN>(p, acc, epi, (long long)tile * BM, n0, tile);
+        // the epilogue's last LDS reads (statistics fold) must finish before the next tile's first staging write
+        __syncthreads();
+    }
 }
 
 // Fold the per-workgroup partial rows: out[c] += sum_r slab[r][c] for c < ncols (row stride = stride).
@@ -576,6 +679,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
+int g_stream_enabled = 1;   // persistent streaming kernel for short-K pure-GEMM convs (cs_set_igemm_path(2) disables it)
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
 
 int igemm_mode(const IgemmParams& p) {
@@ -598,6 +702,33 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.wrow_chunks * 16ull;
     const bool dma = g_igemm_path == 0 && src_bytes < 0x80000000ull && wgt_bytes < 0x80000000ull;
     const int mode = igemm_mode(p);
+    if (dma && mode == 0 && nk_host <= 2 && g_stream_enabled) {
+        // persistent streaming kernel: ~2 workgroups per CU in total, each pinned to one N tile
+        const int n_mtiles = (int)((p.M + BM - 1) / BM);
+        const int n_ntiles = (p.NOUT + BN - 1) / BN;
+        int gx = (512 + n_ntiles - 1) / n_ntiles;
+        if (gx > n_mtiles) gx = n_mtiles;
+        if (gx < 1) gx = 1;
+        dim3 sgrid(gx, n_ntiles, 1);
+        const size_t slds = (size_t)nk_host * (BN + 2 * BM) * 128 + ((size_t)BM * BN * 2 > 16384 ? (size_t)BM * BN * 2 : 16384);
+        auto raise = [&](const void* fn) -> int {
+            if (slds <= 65536) return CS_OK;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess) {
+                cs_set_error_("igemm_stream: cannot raise the dynamic LDS limit");
+                return CS_ERR_LAUNCH;
+            }
+            return CS_OK;
+        };
+        if (nk_host <= 1) {
+            if (raise(reinterpret_cast<const void*>(&igemm_stream_kernel<T, BM, BN, 1>)) != CS_OK) return CS_ERR_LAUNCH;
+            hipLaunchKernelGGL((igemm_stream_kernel<T, BM, BN, 1>), sgrid, dim3(256), slds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes, n_mtiles);
+        } else {
+            if (raise(reinterpret_cast<const void*>(&igemm_stream_kernel<T, BM, BN, 2>)) != CS_OK) return CS_ERR_LAUNCH;
+            hipLaunchKernelGGL((igemm_stream_kernel<T, BM, BN, 2>), sgrid, dim3(256), slds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes, n_mtiles);
+        }
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dma) {
         switch (mode) {
             case 0: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
@@ -671,7 +802,13 @@ extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_ou
 /* The next cs_conv2d_fwd / _dgrad / _wgrad call issued by this thread treats the convolution as GROUPED
  * (groups = C / channels_per_group, C == K, C % 64 == 0) in slab-dense form; see cs_weight_prep_grouped. */
 extern "C" int cs_conv2d_next_is_grouped(void) { g_next_slab = 1; return CS_OK; }
-extern "C" int cs_set_igemm_path(int path) { const int old = g_igemm_path; g_igemm_path = path; return old; }
+extern "C" int cs_set_igemm_path(int path) {
+    // 0 = LDS-DMA + streaming kernel (default), 1 = register-staged everywhere, 2 = LDS-DMA without the streaming kernel
+    const int old = g_igemm_path == 1 ? 1 : (g_stream_enabled ? 0 : 2);
+    g_igemm_path = path == 1 ? 1 : 0;
+    g_stream_enabled = path == 0 ? 1 : 0;
+    return old;
+}
 
 extern "C" size_t cs_conv2d_stats_workspace(long long M, int n_out) {
     // one partial row per M tile; sized for the smallest tile height (64) so every dispatch variant fits
