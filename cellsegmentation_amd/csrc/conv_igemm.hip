@@ -679,7 +679,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
-int g_stream_enabled = 1;   // persistent streaming kernel for short-K pure-GEMM convs (cs_set_igemm_path(2) disables it)
+int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
+                            // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
 
 int igemm_mode(const IgemmParams& p) {
@@ -803,10 +804,10 @@ extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_ou
  * (groups = C / channels_per_group, C == K, C % 64 == 0) in slab-dense form; see cs_weight_prep_grouped. */
 extern "C" int cs_conv2d_next_is_grouped(void) { g_next_slab = 1; return CS_OK; }
 extern "C" int cs_set_igemm_path(int path) {
-    // 0 = LDS-DMA + streaming kernel (default), 1 = register-staged everywhere, 2 = LDS-DMA without the streaming kernel
-    const int old = g_igemm_path == 1 ? 1 : (g_stream_enabled ? 0 : 2);
+    // 0 = LDS-DMA (default), 1 = register-staged everywhere, 3 = LDS-DMA + persistent streaming kernel for short-K 1x1
+    const int old = g_igemm_path == 1 ? 1 : (g_stream_enabled ? 3 : 0);
     g_igemm_path = path == 1 ? 1 : 0;
-    g_stream_enabled = path == 0 ? 1 : 0;
+    g_stream_enabled = path == 3 ? 1 : 0;
     return old;
 }
 

@@ -143,7 +143,7 @@ def _stats_ws(M, n_out, device):
 
 
 def set_igemm_path(path):
-    """0 = LDS-DMA staging (default), 1 = register staging. Returns the previous value."""
+    """0 = LDS-DMA staging (default), 1 = register staging, 3 = LDS-DMA + experimental streaming kernel. Returns the previous value."""
     return _lib.load().cs_set_igemm_path(int(path))
 
 

@@ -108,8 +108,8 @@ size_t cs_conv2d_stats_workspace(long long M, int n_out);
  * (returns BM*1000+BN); lets bench.py / profiles name the kernel instantiation that ran. */
 int cs_igemm_tile(long long M, int n_out);
 /* Staging path of the fwd/dgrad kernel: 0 (default) = LDS-DMA (`buffer_load ... lds`) whenever both operands are
- * < 2 GiB, plus the persistent streaming kernel for short-K 1x1 convolutions; 1 = register-staged everywhere;
- * 2 = LDS-DMA without the streaming kernel.  Returns the previous setting. */
+ * < 2 GiB; 1 = register-staged everywhere; 3 = LDS-DMA plus the experimental persistent streaming kernel for
+ * short-K 1x1 convolutions.  Returns the previous setting. */
 int cs_set_igemm_path(int path);
 /* data gradient: dx = ( conv_transpose(dy, w) + add ) * [mask > 0]; add/mask nullable, both shaped like x.
  *   `mask` is the conv's own input activation when that input came out of a ReLU (the ReLU backward of

@@ -50,7 +50,7 @@ def _relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["lds_dma+stream", "reg_staged", "lds_dma"])
+@pytest.fixture(params=[0, 1, 3], ids=["lds_dma", "reg_staged", "lds_dma+stream"])
 def igemm_path(request):
     old = K.set_igemm_path(request.param)
     yield request.param
