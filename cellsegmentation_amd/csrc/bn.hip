@@ -94,15 +94,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
          idx += (long long)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % CG);
         const long long off = (idx / CG) * C + cg * 8;
-        float v[8];
+        float v[8], mu[8], rs[8], gm[8], bt[8];
         load8<T>(z + off, v);
+        load8p(mean + cg * 8, 0.f, mu);
+        load8p(rstd + cg * 8, 1.f, rs);
+        load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
+        load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            const float g = gamma ? gamma[c] : 1.f;
-            const float b = beta ? beta[c] : 0.f;
-            v[e] = (v[e] - mean[c]) * rstd[c] * g + b;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu[e]) * rs[e] * gm[e] + bt[e];
         if (residual) {
             float r8[8];
             load8<T>(residual + off, r8);
@@ -150,11 +149,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
         if (live) {
             float mu[8], rs[8], gm[8], bt[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                mu[e] = mean[cg * 8 + e]; rs[e] = rstd[cg * 8 + e];
-                gm[e] = gamma ? gamma[cg * 8 + e] : 1.f; bt[e] = beta ? beta[cg * 8 + e] : 0.f;
-            }
+            load8p(mean + cg * 8, 0.f, mu);
+            load8p(rstd + cg * 8, 1.f, rs);
+            load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
+            load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
             for (long long r = r0 + rr; r < r1; r += rpar) {
                 float g[8], zz[8];
                 load8<T>(dy + r * C + cg * 8, g);
@@ -190,16 +188,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
          idx += (long long)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % CG);
         const long long off = (idx / CG) * C + cg * 8;
-        float g[8], zz[8], o[8];
+        float g[8], zz[8], o[8], mu[8], rs[8], gm[8], bt[8];
         load8<T>(dy + off, g);
         load8<T>(z + off, zz);
+        load8p(mean + cg * 8, 0.f, mu);
+        load8p(rstd + cg * 8, 1.f, rs);
+        load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
+        load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cg * 8 + e;
-            const float xh = (zz[e] - mean[c]) * rstd[c];
-            const float gm = gamma ? gamma[c] : 1.f;
-            const float gu = act_grad(g[e], xh, gm, beta ? beta[c] : 0.f, act);
-            o[e] = gm * rstd[c] * (gu - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
+            const float xh = (zz[e] - mu[e]) * rs[e];
+            const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
+            o[e] = gm[e] * rs[e] * (gu - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
         }
         store8<T>(dz + off, o);
     }

@@ -70,6 +70,19 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
     *reinterpret_cast<uint4*>(p) = o;
 }
 
+// 8 consecutive fp32 per-channel parameters (32-byte aligned: channel offsets are multiples of 8) as two 16-byte loads;
+// NULL -> fill value.  Scalar p[c] loads inside an 8-wide loop made the BN kernels instruction-bound (0.6 TB/s).
+__device__ __forceinline__ void load8p(const float* p, float fill, float (&v)[8]) {
+    if (p) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fill;
+    }
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }

@@ -31,18 +31,19 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, co
             for (int kw = 0; kw < R; ++kw) {
                 const int ix = ox * stride - pad + kw;
                 if (ix < 0 || ix >= W) continue;
-                float v[8];
+                float v[8], wp[8];
                 load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
-                const float* wp = w + (kh * R + kw) * C + cg * 8;
+                load8p(w + (kh * R + kw) * C + cg * 8, 0.f, wp);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += v[e] * wp[e];
             }
         }
+        float sc8[8], sh8[8];
+        load8p(scale ? scale + cg * 8 : nullptr, 1.f, sc8);
+        load8p(shift ? shift + cg * 8 : nullptr, 0.f, sh8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float v = acc[e];
-            if (scale) v *= scale[cg * 8 + e];
-            if (shift) v += shift[cg * 8 + e];
+            float v = acc[e] * sc8[e] + sh8[e];
             if (act == CS_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (act == CS_ACT_SILU) v = v / (1.f + __expf(-v));
             acc[e] = v;
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
                 if (tx < 0 || tx % stride != 0) continue;
                 const int ox = tx / stride;
                 if (ox >= Q) continue;
-                float g[8];
+                float g[8], wp[8];
                 load8<T>(dy + ((n * P + oy) * (long long)Q + ox) * C + cg * 8, g);
-                const float* wp = w + (kh * R + kw) * C + cg * 8;
+                load8p(w + (kh * R + kw) * C + cg * 8, 0.f, wp);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += g[e] * wp[e];
             }
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, 
         const int cg = (int)(idx % CG);
         const long long pix = idx / CG;
         const long long n = pix / HW;
-        float v[8];
+        float v[8], sp[8];
         load8<T>(x + pix * C + cg * 8, v);
-        const float* sp = s + n * C + cg * 8;
+        load8p(s + n * C + cg * 8, 1.f, sp);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= sp[e];
         store8<T>(y + pix * C + cg * 8, v);
@@ -183,13 +184,12 @@ __global__ __launch_bounds__(256) void se_dx_kernel(const T* __restrict__ dy, co
         const int cg = (int)(idx % CG);
         const long long pix = idx / CG;
         const long long n = pix / HW;
-        float g[8];
+        float g[8], s8[8], d8[8];
         load8<T>(dy + pix * C + cg * 8, g);
+        load8p(s + n * C + cg * 8, 1.f, s8);
+        load8p(davg ? davg + n * C + cg * 8 : nullptr, 0.f, d8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const long long o = n * C + cg * 8 + e;
-            g[e] = g[e] * s[o] + (davg ? davg[o] * inv : 0.f);
-        }
+        for (int e = 0; e < 8; ++e) g[e] = g[e] * s8[e] + d8[e] * inv;
         store8<T>(dx + pix * C + cg * 8, g);
     }
 }

@@ -171,12 +171,16 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
         const long long t = idx / CG;
         const int p = (int)(t % HW);
         const long long n = t / HW;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float g = dfeat[n * C + cg * 8 + e];
-            v[e] = g * inv + ((with_max && amax[n * C + cg * 8 + e] == p) ? g : 0.f);
+        float v[8], g8[8];
+        load8p(dfeat + n * C + cg * 8, 0.f, g8);
+        int am[8];
+        if (with_max) {
+            const int4 a0 = *reinterpret_cast<const int4*>(amax + n * C + cg * 8);
+            const int4 a1 = *reinterpret_cast<const int4*>(amax + n * C + cg * 8 + 4);
+            am[0] = a0.x; am[1] = a0.y; am[2] = a0.z; am[3] = a0.w; am[4] = a1.x; am[5] = a1.y; am[6] = a1.z; am[7] = a1.w;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = g8[e] * inv + ((with_max && am[e] == p) ? g8[e] : 0.f);
         const long long o = (n * HW + p) * C + cg * 8;
         if (relu_mask) {
             float xx[8];
