@@ -68,6 +68,7 @@ _SIGNATURES = {
     "cs_bilinear_ac_bwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_concat_channels": (c_int, [_P, _P, c_int, _P, c_longlong, c_int, c_int, _P]),
     "cs_split_channels": (c_int, [_P, c_int, _P, _P, c_longlong, c_int, c_int, _P]),
+    "cs_tile_gather": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_longlong, c_int, POINTER(c_float), POINTER(c_float), c_int, _P, _P]),
     "cs_dice_fwd": (c_int, [_P, _P, c_int, c_longlong, c_float, c_int, _P, _P, _P]),
     "cs_dice_bwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_float, c_int, _P, _P]),
     "cs_softmax_channel_fwd": (c_int, [_P, _P, c_int, c_int, c_longlong, c_int, _P]),

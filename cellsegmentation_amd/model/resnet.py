@@ -259,7 +259,10 @@ class MILResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("cellsegmentation_amd models run on the GPU only (HIP kernels, no CPU fallback); "
                                "move the model and its input to a cuda device")
-        xh = HF.to_nhwc(x.float(), self.compute_dtype)
+        if x.dim() == 4 and x.shape[-1] == 8 and x.shape[1] != 3 and x.dtype == self.compute_dtype:
+            xh = x                      # already staged NHWC tiles (cellsegmentation_amd.tiles.gather_tiles)
+        else:
+            xh = HF.to_nhwc(x.float(), self.compute_dtype)
         return E.run_plan(self._encoder_plan(with_skips), [xh], self.compute_dtype, bn_train, self.use_tr_read)
 
     def _image_branch(self, seq, feat):

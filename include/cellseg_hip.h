@@ -193,6 +193,14 @@ int cs_se_scale_bwd(const void* dy, const void* x, int dtype, const float* s, co
 int cs_rowscale_add(const void* a, int dtype, const float* row_scale, const void* b, void* y, int N, long long per_row,
                     void* stream);
 
+/* ---- tile construction on the device (the step before the hot path; dataset/dataset.py:203-214,718-742,78-83) ----
+ * images: uint8 [n_images][H][W][3] in HBM; tile t = image tile_img[t], upper-left (row, col) = tile_rc[2t], tile_rc[2t+1];
+ * out[n_tiles][size][size][8] dtype = ((u8/255) - mean)/std on channels 0..2, channels 3..7 zero (the NHWC operand of the
+ * stem convolution).  mean/std are HOST arrays of 3 floats.  The caller guarantees tiles lie inside the image. */
+int cs_tile_gather(const uint8_t* images, int n_images, int H, int W, const int32_t* tile_img, const int32_t* tile_rc,
+                   long long n_tiles, int size, const float* host_mean3, const float* host_std3, int dtype, void* out,
+                   void* stream);
+
 /* ---- heads: Linear (resnet.py:126,137,140,150), losses (train/train.py:34,80-83) ------------- */
 /* y[M][N] = act( x[M][K] @ w[N][K]^T + b[N] )  (fp32; b nullable; preact nullable: the value before act) */
 int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, float* preact, int M, int N, int K, int act,

@@ -119,3 +119,14 @@ def test_synth_is_deterministic_and_name_keyed():
     assert t1.dtype == np.uint8 and np.array_equal(t1, t2)
     x = synth.normalise(t1)
     assert tuple(x.shape) == (2, 3, 64, 64) and -2.2 < float(x.min()) and float(x.max()) < 2.7
+
+
+def test_get_tiles_host_grid_matches_reference_known_answer():
+    from cellsegmentation_amd import tiles
+    g = tiles.get_tiles((299, 299), 20, 32)                  # 15 x 15 = 225 coords, last origin 267
+    assert len(g) == 225 and g[0] == (0, 0) and g[14] == (0, 267) and g[-1] == (267, 267)
+    assert g == orc.get_tiles_coords(299, 299, 20, 32)
+    assert len(tiles.get_tiles((299, 299), 5, 16)) == 3364   # train_seg.py:225-232: 58 x 58
+    assert tiles.get_tiles((64, 64), 32, 32) == [(0, 0), (0, 32), (32, 0), (32, 32)]     # stride lands on the border: no extra tile
+    ti, rc = tiles.tile_index(2, (64, 64), 32, 32)
+    assert ti.tolist() == [0] * 4 + [1] * 4 and rc.shape == (8, 2)

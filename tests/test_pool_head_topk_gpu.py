@@ -161,3 +161,30 @@ def test_topk_single_group_wraps(dev):
     got = _run_topk(probs, [0] * 64, {0: 0}, 1, 30, dev)
     ref = _sample_reference(probs, [0] * 64, {0: 0}, 1, 30)
     assert got.tolist() == ref.tolist() == []
+
+
+def test_tile_gather_matches_get_tiles_totensor_normalize(dev):
+    """device tile construction == reference get_tiles + ToTensor + Normalize (via the oracle)."""
+    from cellsegmentation_amd import synth, tiles
+    from oracle import cellseg_oracle as orc
+    imgs = synth.ihc_tiles(3, 299, 77)                      # uint8 [3,299,299,3]
+    coords = tiles.get_tiles((299, 299), 20, 32)
+    assert coords == orc.get_tiles_coords(299, 299, 20, 32) and len(coords) == 225 and coords[-1] == (267, 267)
+    ti, rc = tiles.tile_index(3, (299, 299), 20, 32)
+    assert len(ti) == 675 and ti[224] == 0 and ti[225] == 1
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        out = tiles.gather_tiles(torch.from_numpy(imgs).to(dev), ti, rc, 32, dtype)
+        torch.cuda.synchronize()
+        ref = torch.stack([synth.normalise(imgs[i:i + 1, r:r + 32, c:c + 32])[0] for i, (r, c) in zip(ti.tolist(), rc.tolist())])
+        got = out[..., :3].float().cpu().permute(0, 3, 1, 2)
+        assert float((got - ref).abs().max()) <= tol
+        assert float(out[..., 3:].float().abs().max()) == 0.0
+    # staged tiles feed the model directly (no NCHW detour)
+    from cellsegmentation_amd.model import resnet as R
+    m = R.MILresnet18()
+    sd = m.state_dict(); synth.fill_state_dict(sd); m.load_state_dict(sd)
+    m = m.to(dev).set_compute_dtype(torch.float32); m.setmode("tile"); m.eval()
+    with torch.no_grad():
+        a = m(tiles.gather_tiles(torch.from_numpy(imgs).to(dev), ti[:16], rc[:16], 32, torch.float32))
+        b = m(ref[:16].to(dev))
+    assert float((a - b).abs().max()) < 1e-5
