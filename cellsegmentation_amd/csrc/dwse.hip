@@ -107,17 +107,19 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    long long n = p0 / ((long long)P * Q);
+    int rem = (int)(p0 - n * (long long)P * Q);
+    int oy = rem / Q, ox = rem - oy * Q;
     for (long long pp = p0; pp < p1; ++pp) {
-        const long long n = pp / ((long long)P * Q);
-        const int rem = (int)(pp - n * (long long)P * Q);
-        const int oy = rem / Q, ox = rem - oy * Q;
         const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-        float g[8], v[8];
-        load8<T>(dy + pp * C + cg * 8, g);
-        load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            float g[8], v[8];
+            load8<T>(dy + pp * C + cg * 8, g);
+            load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+            for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+        }
+        if (++ox == Q) { ox = 0; if (++oy == P) { oy = 0; ++n; } }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) atomicAdd(dw + tap * C + cg * 8 + e, acc[e]);
@@ -144,17 +146,22 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, 
 
 // ds[n,c] = sum_p dy[n,p,c] * x[n,p,c]   (workgroup = (64 channel groups x 4 pixel lanes), one image)
 template <typename T>
-__global__ __launch_bounds__(256) void se_ds_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ ds, int HW, int C) {
+__global__ __launch_bounds__(256) void se_ds_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ ds, int HW, int C,
+                                                    int slab) {
+    // grid = (channel-group chunks, N, pixel slabs): partial sums combined with one atomic per channel (ds zeroed by launcher)
     const int CG = C / 8;
     const int n = blockIdx.y;
     const int cg = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
+    const int p0 = blockIdx.z * slab;
+    int p1 = p0 + slab;
+    if (p1 > HW) p1 = HW;
     __shared__ float red[4][64][8];
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     if (cg < CG) {
-        for (int p = part; p < HW; p += 4) {
+        for (int p = p0 + part; p < p1; p += 4) {
             float g[8], v[8];
             const long long o = ((long long)n * HW + p) * C + cg * 8;
             load8<T>(dy + o, g);
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void se_ds_kernel(const T* __restrict__ dy, co
     if (part == 0 && cg < CG) {
         const int l = threadIdx.x & 63;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ds[(long long)n * C + cg * 8 + e] = red[0][l][e] + red[1][l][e] + red[2][l][e] + red[3][l][e];
+        for (int e = 0; e < 8; ++e) atomicAdd(ds + (long long)n * C + cg * 8 + e, red[0][l][e] + red[1][l][e] + red[2][l][e] + red[3][l][e]);
     }
 }
 
@@ -274,8 +281,8 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     CS_CHECK_ARG(x && dy && dw_hwc, "dwconv_wgrad: NULL tensor");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long npix = (long long)g->N * g->P * g->Q;
-    long long ppb = (npix + 1023) / 1024;
-    if (ppb < 64) ppb = 64;
+    long long ppb = (npix + 4095) / 4096;          // ~4096 pixel slabs x (taps*C/8 / 256) item groups
+    if (ppb < 32) ppb = 32;
     const int work = g->R * g->R * (g->C / 8);
     dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)((work + 255) / 256));
     CS_T_SWITCH(dtype, "dwconv_wgrad",
@@ -305,10 +312,14 @@ extern "C" int cs_se_scale_bwd(const void* dy, const void* x, int dtype, const f
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (phase == 0) {
         CS_CHECK_ARG(x && ds, "se_scale_bwd: phase 0 needs x and ds");
-        dim3 grid((C / 8 + 63) / 64, N);
+        int slabs = (HW + 511) / 512;
+        if (slabs > 64) slabs = 64;
+        const int slab = (HW + slabs - 1) / slabs;
+        if (hipMemsetAsync(ds, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) { cs_set_error_("se_scale_bwd: memset failed"); return CS_ERR_LAUNCH; }
+        dim3 grid((C / 8 + 63) / 64, N, (HW + slab - 1) / slab);
         CS_T_SWITCH(dtype, "se_scale_bwd",
-                    hipLaunchKernelGGL(se_ds_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, ds, HW, C),
-                    hipLaunchKernelGGL(se_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, ds, HW, C));
+                    hipLaunchKernelGGL(se_ds_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, ds, HW, C, slab),
+                    hipLaunchKernelGGL(se_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, ds, HW, C, slab));
     } else {
         CS_CHECK_ARG(s && dx, "se_scale_bwd: phase 1 needs s and dx");
         const int grid = grid_ew((long long)N * HW * (C / 8));

@@ -41,19 +41,22 @@ __device__ __forceinline__ float lin_act_grad(float g, float yv, int act) {
     return g;
 }
 
-// dx[m][k] = sum_n g[m][n] w[n][k]
+// dx[m][k] = sum_n g[m][n] w[n][k]: one wave per output, lanes stride over n (N reaches 2304 in the SE blocks: a
+// thread-per-output loop was a 2304-long serial chain on a 24-workgroup grid)
 __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                         const float* __restrict__ w, float* __restrict__ dx, int M, int N,
                                                         int K, int act) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)M * K) return;
-    const int m = (int)(idx / K), k = (int)(idx % K);
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= (long long)M * K) return;
+    const int m = (int)(wave / K), k = (int)(wave % K);
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         const float g = lin_act_grad(dy[(long long)m * N + n], act ? y[(long long)m * N + n] : 0.f, act);
         acc += g * w[(long long)n * K + k];
     }
-    dx[idx] = acc;
+    acc = wave_sum(acc);
+    if (lane == 0) dx[wave] = acc;
 }
 
 // dw[n][k] = sum_m g[m][n] x[m][k];  db[n] = sum_m g[m][n] (k == 0 thread)
@@ -230,8 +233,8 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dx) {
         CS_CHECK_ARG(w, "linear_bwd: dx needs w");
-        const long long tot = (long long)M * K;
-        hipLaunchKernelGGL(linear_dx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dy, y, w, dx, M, N, K, act);
+        const long long waves = (long long)M * K;
+        hipLaunchKernelGGL(linear_dx_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, dy, y, w, dx, M, N, K, act);
         CS_LAUNCH_CHECK();
     }
     if (dw) {

@@ -158,6 +158,41 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, f
     }
 }
 
+// Average only (the SE squeeze, HW up to 150*150): many workgroups per image, each reduces a slab of pixels and adds its
+// partial mean with one atomic per channel (feat zeroed by the launcher).  grid = (channel-group chunks, N, pixel slabs).
+template <typename T>
+__global__ __launch_bounds__(256) void gap_avg_split_kernel(const T* __restrict__ x, float* __restrict__ feat, int HW, int C, int slab) {
+    const int CG = C / 8;
+    const int n = blockIdx.y;
+    const int cg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int p0 = blockIdx.z * slab;
+    int p1 = p0 + slab;
+    if (p1 > HW) p1 = HW;
+    __shared__ float red[4][64][8];
+    float sum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+    if (cg < CG) {
+        for (int p = p0 + part; p < p1; p += 4) {
+            float v[8];
+            load8<T>(x + ((long long)n * HW + p) * C + cg * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[part][threadIdx.x & 63][e] = sum[e];
+    __syncthreads();
+    if (part == 0 && cg < CG) {
+        const int l = threadIdx.x & 63;
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            atomicAdd(feat + (long long)n * C + cg * 8 + e, (red[0][l][e] + red[1][l][e] + red[2][l][e] + red[3][l][e]) * inv);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dfeat, const int32_t* __restrict__ amax,
                                                       const T* __restrict__ x, T* __restrict__ dx, int N, int HW, int C,
@@ -241,6 +276,21 @@ extern "C" int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t*
     CS_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad extents");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((C / 8 + 63) / 64, N);
+    if (!with_max && HW >= 1024) {
+        int slabs = (HW + 511) / 512;
+        if (slabs > 64) slabs = 64;
+        const int slab = (HW + slabs - 1) / slabs;
+        if (hipMemsetAsync(feat, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) { cs_set_error_("gap_fwd: memset failed"); return CS_ERR_LAUNCH; }
+        dim3 g3((C / 8 + 63) / 64, N, (HW + slab - 1) / slab);
+        if (dtype == CS_F32)
+            hipLaunchKernelGGL(gap_avg_split_kernel<float>, g3, dim3(256), 0, st, (const float*)x, feat, HW, C, slab);
+        else if (dtype == CS_BF16)
+            hipLaunchKernelGGL(gap_avg_split_kernel<bf16_t>, g3, dim3(256), 0, st, (const bf16_t*)x, feat, HW, C, slab);
+        else
+            CS_CHECK_ARG(false, "gap_fwd: bad dtype");
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dtype == CS_F32)
         hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, feat, argmax, HW, C, with_max);
     else if (dtype == CS_BF16)
