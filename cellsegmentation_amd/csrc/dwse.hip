@@ -88,41 +88,59 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
     }
 }
 
-// dw[kh][kw][c] += sum over a slab of output pixels of dy * x.  Thread = (tap, channel group), workgroup = slab of
-// `pix_per_block` output pixels: each thread issues 8 atomics per slab (spread over R*R*C addresses).
+// dw[kh][kw][c] += sum over output pixels of dy * x.  Workgroup = (slab of output pixels) x (chunk of <= 64 channel groups);
+// threads = W channel groups x (256/W) pixel lanes.  Taps are the OUTER loop: per tap every thread accumulates its pixels
+// for 8 channels, the pixel lanes are folded through LDS and ONE atomic per (tap, channel) leaves the workgroup
+// (the first version issued 8 atomics per thread per slab and was atomic-bound).
 template <typename T>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int N,
                                                        int H, int W, int C, int R, int stride, int pad, int P, int Q, int pix_per_block) {
     const int CG = C / 8;
-    const int work = R * R * CG;
-    const int item = blockIdx.y * blockDim.x + threadIdx.x;
-    if (item >= work) return;
-    const int cg = item % CG;
-    const int tap = item / CG;
-    const int kh = tap / R, kw = tap - kh * R;
+    const int cg0 = blockIdx.y * 64;
+    const int width = (CG - cg0) < 64 ? (CG - cg0) : 64;
+    const int lanes = 256 / width;
+    const int cgl = threadIdx.x % width;
+    const int pl = threadIdx.x / width;
+    const int cg = cg0 + cgl;
+    const bool live = pl < lanes;
     const long long npix = (long long)N * P * Q;
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     long long p1 = p0 + pix_per_block;
     if (p1 > npix) p1 = npix;
-    float acc[8];
+    __shared__ float red[256][8];
+    for (int kh = 0; kh < R; ++kh) {
+        for (int kw = 0; kw < R; ++kw) {
+            float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    long long n = p0 / ((long long)P * Q);
-    int rem = (int)(p0 - n * (long long)P * Q);
-    int oy = rem / Q, ox = rem - oy * Q;
-    for (long long pp = p0; pp < p1; ++pp) {
-        const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            float g[8], v[8];
-            load8<T>(dy + pp * C + cg * 8, g);
-            load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            if (live) {
+                for (long long pp = p0 + pl; pp < p1; pp += lanes) {
+                    const long long n = pp / ((long long)P * Q);
+                    const int rem = (int)(pp - n * (long long)P * Q);
+                    const int oy = rem / Q, ox = rem - oy * Q;
+                    const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                    float g[8], v[8];
+                    load8<T>(dy + pp * C + cg * 8, g);
+                    load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+                    for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = live ? acc[e] : 0.f;
+            __syncthreads();
+            if ((int)threadIdx.x < width) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = 0.f;
+                    for (int r = 0; r < lanes; ++r) t += red[r * width + threadIdx.x][e];
+                    atomicAdd(dw + (kh * R + kw) * C + cg * 8 + e, t);
+                }
+            }
         }
-        if (++ox == Q) { ox = 0; if (++oy == P) { oy = 0; ++n; } }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dw + tap * C + cg * 8 + e, acc[e]);
 }
 
 // y[n,p,c] = x[n,p,c] * s[n,c]
@@ -281,10 +299,12 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     CS_CHECK_ARG(x && dy && dw_hwc, "dwconv_wgrad: NULL tensor");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long npix = (long long)g->N * g->P * g->Q;
-    long long ppb = (npix + 4095) / 4096;          // ~4096 pixel slabs x (taps*C/8 / 256) item groups
-    if (ppb < 32) ppb = 32;
-    const int work = g->R * g->R * (g->C / 8);
-    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)((work + 255) / 256));
+    const int chunks = (g->C / 8 + 63) / 64;
+    long long slabs = 1024 / chunks;               // ~1024 workgroups in total
+    if (slabs < 1) slabs = 1;
+    long long ppb = (npix + slabs - 1) / slabs;
+    if (ppb < 64) ppb = 64;
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)chunks);
     CS_T_SWITCH(dtype, "dwconv_wgrad",
                 hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, dw_hwc, g->N, g->H, g->W,
                                    g->C, g->R, g->stride, g->pad, g->P, g->Q, (int)ppb),
