@@ -108,21 +108,31 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
     long long p1 = p0 + pix_per_block;
     if (p1 > npix) p1 = npix;
     __shared__ float red[256][8];
+    // pixel coordinates of the slab, decoded once (a division per pixel per tap dominated the first version)
+    __shared__ int s_row[1024], s_iy[1024], s_ix[1024];     // n*H, oy*stride-pad, ox*stride-pad
+    const int cnt = (int)(p1 - p0);
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long long pp = p0 + i;
+        const int n = (int)(pp / ((long long)P * Q));
+        const int rem = (int)(pp - (long long)n * P * Q);
+        const int oy = rem / Q;
+        s_row[i] = n * H;
+        s_iy[i] = oy * stride - pad;
+        s_ix[i] = (rem - oy * Q) * stride - pad;
+    }
+    __syncthreads();
     for (int kh = 0; kh < R; ++kh) {
         for (int kw = 0; kw < R; ++kw) {
             float acc[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
             if (live) {
-                for (long long pp = p0 + pl; pp < p1; pp += lanes) {
-                    const long long n = pp / ((long long)P * Q);
-                    const int rem = (int)(pp - n * (long long)P * Q);
-                    const int oy = rem / Q, ox = rem - oy * Q;
-                    const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                for (int i = pl; i < cnt; i += lanes) {
+                    const int iy = s_iy[i] + kh, ix = s_ix[i] + kw;
                     if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
                     float g[8], v[8];
-                    load8<T>(dy + pp * C + cg * 8, g);
-                    load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+                    load8<T>(dy + (p0 + i) * C + cg * 8, g);
+                    load8<T>(x + ((long long)(s_row[i] + iy) * W + ix) * C + cg * 8, v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
                 }
@@ -304,6 +314,7 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     if (slabs < 1) slabs = 1;
     long long ppb = (npix + slabs - 1) / slabs;
     if (ppb < 64) ppb = 64;
+    if (ppb > 1024) ppb = 1024;                    // LDS coordinate table
     dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)chunks);
     CS_T_SWITCH(dtype, "dwconv_wgrad",
                 hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, dw_hwc, g->N, g->H, g->W,
