@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
     }
 }
 
-// dw[kh][kw][c] += sum over output pixels of dy * x.  Workgroup = (slab of output pixels) x (chunk of <= 64 channel groups);
-// threads = W channel groups x (256/W) pixel lanes.  Taps are the OUTER loop: per tap every thread accumulates its pixels
-// for 8 channels, the pixel lanes are folded through LDS and ONE atomic per (tap, channel) leaves the workgroup
-// (the first version issued 8 atomics per thread per slab and was atomic-bound).
+// dw[kh][kw][c] += sum over output pixels of dy * x.  Workgroup = (slab of output pixels) x (chunk of <= 64 channel groups)
+// x (group of <= 9 filter taps); threads = W channel groups x (256/W) pixel lanes.  Pixels are the OUTER loop: dy is read once
+// per pixel and each of the group's taps keeps its own 8-channel accumulator in registers (72 VGPRs); afterwards the pixel
+// lanes are folded through LDS and ONE atomic per (tap, channel) leaves the workgroup.
+constexpr int kDwTaps = 9;
 template <typename T>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int N,
                                                        int H, int W, int C, int R, int stride, int pad, int P, int Q, int pix_per_block) {
@@ -103,51 +104,58 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
     const int pl = threadIdx.x / width;
     const int cg = cg0 + cgl;
     const bool live = pl < lanes;
+    const int t0 = blockIdx.z * kDwTaps;
+    const int nt = (R * R - t0) < kDwTaps ? (R * R - t0) : kDwTaps;
     const long long npix = (long long)N * P * Q;
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     long long p1 = p0 + pix_per_block;
     if (p1 > npix) p1 = npix;
-    __shared__ float red[256][8];
-    // pixel coordinates of the slab, decoded once (a division per pixel per tap dominated the first version)
-    __shared__ int s_row[1024], s_iy[1024], s_ix[1024];     // n*H, oy*stride-pad, ox*stride-pad
-    const int cnt = (int)(p1 - p0);
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long long pp = p0 + i;
-        const int n = (int)(pp / ((long long)P * Q));
-        const int rem = (int)(pp - (long long)n * P * Q);
-        const int oy = rem / Q;
-        s_row[i] = n * H;
-        s_iy[i] = oy * stride - pad;
-        s_ix[i] = (rem - oy * Q) * stride - pad;
-    }
-    __syncthreads();
-    for (int kh = 0; kh < R; ++kh) {
-        for (int kw = 0; kw < R; ++kw) {
-            float acc[8];
+    float acc[kDwTaps][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-            if (live) {
-                for (int i = pl; i < cnt; i += lanes) {
-                    const int iy = s_iy[i] + kh, ix = s_ix[i] + kw;
-                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                    float g[8], v[8];
-                    load8<T>(dy + (p0 + i) * C + cg * 8, g);
-                    load8<T>(x + ((long long)(s_row[i] + iy) * W + ix) * C + cg * 8, v);
+    for (int t = 0; t < kDwTaps; ++t)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += g[e] * v[e];
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    if (live) {
+        long long pp = p0 + pl;
+        long long n = pp / ((long long)P * Q);
+        int rem = (int)(pp - n * (long long)P * Q);
+        int oy = rem / Q, ox = rem - oy * Q;
+        for (; pp < p1; pp += lanes) {
+            float g[8];
+            load8<T>(dy + pp * C + cg * 8, g);
+            const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+#pragma unroll
+            for (int t = 0; t < kDwTaps; ++t) {
+                if (t < nt) {
+                    const int tap = t0 + t;
+                    const int kh = tap / R, kw = tap - kh * R;
+                    const int iy = iy0 + kh, ix = ix0 + kw;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                        float v[8];
+                        load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[t][e] += g[e] * v[e];
+                    }
                 }
             }
-            __syncthreads();
+            ox += lanes;
+            while (ox >= Q) { ox -= Q; if (++oy == P) { oy = 0; ++n; } }
+        }
+    }
+    __shared__ float red[256][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = live ? acc[e] : 0.f;
-            __syncthreads();
-            if ((int)threadIdx.x < width) {
+    for (int t = 0; t < kDwTaps; ++t) {
+        if (t >= nt) break;
+        __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = 0.f;
-                    for (int r = 0; r < lanes; ++r) t += red[r * width + threadIdx.x][e];
-                    atomicAdd(dw + (kh * R + kw) * C + cg * 8 + e, t);
-                }
+        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = live ? acc[t][e] : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < width) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sum = 0.f;
+                for (int r = 0; r < lanes; ++r) sum += red[r * width + threadIdx.x][e];
+                atomicAdd(dw + (t0 + t) * C + cg * 8 + e, sum);
             }
         }
     }
@@ -310,12 +318,12 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long npix = (long long)g->N * g->P * g->Q;
     const int chunks = (g->C / 8 + 63) / 64;
-    long long slabs = 1024 / chunks;               // ~1024 workgroups in total
+    const int tgroups = (g->R * g->R + kDwTaps - 1) / kDwTaps;
+    long long slabs = 1024 / (chunks * tgroups);   // ~1024 workgroups in total
     if (slabs < 1) slabs = 1;
     long long ppb = (npix + slabs - 1) / slabs;
     if (ppb < 64) ppb = 64;
-    if (ppb > 1024) ppb = 1024;                    // LDS coordinate table
-    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)chunks);
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)chunks, (unsigned)tgroups);
     CS_T_SWITCH(dtype, "dwconv_wgrad",
                 hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, dw_hwc, g->N, g->H, g->W,
                                    g->C, g->R, g->stride, g->pad, g->P, g->Q, (int)ppb),
