@@ -145,17 +145,19 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
     __shared__ float red[256][8];
 #pragma unroll
     for (int t = 0; t < kDwTaps; ++t) {
-        if (t >= nt) break;
-        __syncthreads();
+        // nt is workgroup-uniform; no early exit so the loop fully unrolls and acc[t] stays in registers
+        if (t < nt) {
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = live ? acc[t][e] : 0.f;
-        __syncthreads();
-        if ((int)threadIdx.x < width) {
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = live ? acc[t][e] : 0.f;
+            __syncthreads();
+            if ((int)threadIdx.x < width) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float sum = 0.f;
-                for (int r = 0; r < lanes; ++r) sum += red[r * width + threadIdx.x][e];
-                atomicAdd(dw + (t0 + t) * C + cg * 8 + e, sum);
+                for (int e = 0; e < 8; ++e) {
+                    float sum = 0.f;
+                    for (int r = 0; r < lanes; ++r) sum += red[r * width + threadIdx.x][e];
+                    atomicAdd(dw + (t0 + t) * C + cg * 8 + e, sum);
+                }
             }
         }
     }
