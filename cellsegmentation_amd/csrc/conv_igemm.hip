@@ -121,28 +121,35 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     }
         }
         __syncthreads();
+        // element offset of this thread's first row of the half; identity row->pixel mapping advances by a constant per iteration
+        const long long row0 = m0 + half * HROWS + tid / CG;
+        const long long off0 = row0 * p.NOUT + o;
+        const long long off_step = (long long)(256 / CG) * p.NOUT;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int hrow = it * (256 / CG) + tid / CG;
-            const int row = half * HROWS + hrow;
-            const long long m = m0 + row;
+            const long long m = row0 + it * (256 / CG);
             if (m < p.M && ook) {
                 float v[8];
                 const float4 c0 = *reinterpret_cast<const float4*>(Cs + hrow * BN + cg * 8);
                 const float4 c1 = *reinterpret_cast<const float4*>(Cs + hrow * BN + cg * 8 + 4);
                 v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
                 v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-                long long dpix = m;
+                long long off = off0 + it * off_step;
                 if (p.dst_step != 1) {
                     const long long img = m / ((long long)p.DH * p.DW);
                     const int rem = (int)(m - img * (long long)p.DH * p.DW);
                     const int a = rem / p.DW;
                     const int b = rem - a * p.DW;
-                    dpix = (img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox;
+                    off = ((img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox) * p.NOUT + o;
                 }
-                const long long off = dpix * p.NOUT + o;
+                if (p.scale) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += sh[e];
+                }
                 if (res) {
                     float r8[8];
                     load8<T>(res + off, r8);
