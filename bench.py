@@ -121,10 +121,22 @@ def roofline_from(records, steps, dtype):
         achieved, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
     else:
         achieved, peak, unit, bound = fl / (ms * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")          # separate PMC passes, tools/collect_traffic.py
+    if os.path.exists(tpath):
+        try:
+            entry = json.load(open(tpath))["kernels"].get(dom.split(" x")[0])
+            if entry:
+                # the timed kernel mix may differ slightly from the sampled one; this is the per-launch average of the PMC run
+                traffic = {"hbm_bytes_per_launch": entry["hbm_bytes_per_launch"], "read": entry["read_bytes_per_launch"],
+                           "write": entry["write_bytes_per_launch"], "vs_algorithmic": round(entry["hbm_bytes_per_launch"] / (by / n), 2),
+                           "source": "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"}
+        except (ValueError, KeyError):
+            traffic = None
     three = [v for k, v in per_family.items() if k.startswith("3x3")]
     t3 = sum(v[0] for v in three) / (sum(v[1] for v in three) * 1e-3) / 1e12 if three else None
     return {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-            "traffic": None, "kernel": dom, "avg_launch_ms": round(ms / n, 4), "launches": n,
+            "traffic": traffic, "kernel": dom, "avg_launch_ms": round(ms / n, 4), "launches": n,
             "algorithmic_per_launch": {"gflop": round(fl / n / 1e9, 3), "mbytes": round(by / n / 1e6, 2), "flop_per_byte": round(fl / by, 1)},
             "conv3x3_family_tflops": round(t3, 2) if t3 else None, "conv3x3_family_frac_of_mfma_peak": round(t3 / peak_tf, 4) if t3 else None,
             "by_kernel": {k: row(v) for k, v in sorted(per_kernel.items())},
