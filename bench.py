@@ -53,9 +53,10 @@ MACHINE_BALANCE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)     # FLOP per 
 
 
 def conv_flops(g):
-    """Algorithmic FLOPs of one conv-family launch: 2*N*P*Q*K*C*R*S with the TRUE channel counts (stem C=3, not the padded 8)."""
+    """Algorithmic FLOPs of one conv-family launch: 2*N*P*Q*K*C*R*S with the TRUE channel counts (stem C=3, not the padded 8);
+    a batched weight-gradient launch covers g["batch"] layers of that geometry."""
     c_true = 3 if (g["R"] == 7 and g["C"] == 8) else g["C"]
-    return 2.0 * g["N"] * g["P"] * g["Q"] * g["K"] * c_true * g["R"] * g["S"]
+    return 2.0 * g["N"] * g["P"] * g["Q"] * g["K"] * c_true * g["R"] * g["S"] * g.get("batch", 1)
 
 
 def conv_bytes(kind, g, es):
@@ -68,7 +69,7 @@ def conv_bytes(kind, g, es):
         return x + y + w * es + g["extra"] * y
     if kind == "dgrad":
         return y + x + w * es + g["extra"] * x
-    return x + y + w * 4
+    return (x + y + w * 4) * g.get("batch", 1)
 
 
 def kernel_name(kind, g, dtype):

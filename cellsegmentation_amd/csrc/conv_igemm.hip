@@ -944,6 +944,11 @@ struct WgradParams {
     int SCc;          // C / chunk
     long long m_per_split;   // multiple of the K-step
     long long slab_stride;   // elements between split-K slabs (KO*QE)
+    // batched launch over n identical-geometry layers: blockIdx.z = item * nsplit + slice; tables live in device memory
+    const void* const* x_tab;
+    const void* const* dy_tab;
+    float* const* dw_tab;
+    int nsplit;
 };
 
 template <typename T, int BM, int BN, bool TR>
@@ -973,13 +978,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
     const int k0 = blockIdx.x * BM;          // output-channel tile origin
     const int q0 = blockIdx.y * BN;          // K-space (tap,c) element origin
-    const long long mbeg = (long long)blockIdx.z * p.m_per_split;
+    const int item = p.x_tab ? (int)(blockIdx.z / p.nsplit) : 0;
+    const int slice = p.x_tab ? (int)(blockIdx.z % p.nsplit) : (int)blockIdx.z;
+    const long long mbeg = (long long)slice * p.m_per_split;
     long long mend = mbeg + p.m_per_split;
     if (mend > p.M) mend = p.M;
     // (slices are non-empty by construction: nsplit = ceil(M / m_per_split); an empty one would still write zeros)
 
-    const T* __restrict__ xs = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ gs = reinterpret_cast<const T*>(p.dy);
+    const T* __restrict__ xs = reinterpret_cast<const T*>(p.x_tab ? p.x_tab[item] : p.x);
+    const T* __restrict__ gs = reinterpret_cast<const T*>(p.x_tab ? p.dy_tab[item] : p.dy);
+    float* __restrict__ dw_base = p.x_tab ? p.dw_tab[item] : p.dw;
 
     // A operand (dy): chunk column fixed per thread
     const int ac = tid % ACPR;
@@ -1147,7 +1155,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     // ---- split-K partials: slice z writes its tile into slab z with PLAIN stores (32 consecutive q per half-wave =
     // 128-B segments).  fp32 atomics run at ~1.3 TB/s chip-wide and were the floor of this kernel (~50 us per launch);
     // plain stores are ~5x faster, need no zero-fill, and the fold over slabs (cs_wgrad_finalize) is deterministic.
-    float* slab = p.dw + (long long)blockIdx.z * p.slab_stride;
+    float* slab = dw_base + (long long)slice * p.slab_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1163,8 +1171,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
 // number of split-K slices for KO x QE outputs over M pixels with a BM x 128 tile: ~512 workgroups (2 per CU);
 // every slice costs one extra write + read of the whole dW in fp32, so no more than needed to fill the chip
-int wgrad_splits(long long M, int KO, int QE, int BM) {
-    const int tiles = cs_ceil_div(KO, BM) * cs_ceil_div(QE, 128);
+int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
+    const int tiles = cs_ceil_div(KO, BM) * cs_ceil_div(QE, 128) * (n_items > 1 ? n_items : 1);
     long long want = (512 + tiles - 1) / tiles;
     const long long max_split = (M + 63) / 64;
     if (want > max_split) want = max_split;
@@ -1175,16 +1183,17 @@ int wgrad_splits(long long M, int KO, int QE, int BM) {
 }
 
 template <typename T, int BM, int BN, bool TR>
-int launch_wgrad(WgradParams p, hipStream_t st) {
+int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
     constexpr int BKP = 32;
     constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
-    const int nsplit = wgrad_splits(p.M, p.KO, p.QE, BM);
+    const int nsplit = wgrad_splits(p.M, p.KO, p.QE, BM, n_items);
+    p.nsplit = nsplit;
     long long per = (p.M + nsplit - 1) / nsplit;
     per = ((per + BKP - 1) / BKP) * BKP;
     p.m_per_split = per;
     p.slab_stride = (long long)p.KO * p.QE;
     constexpr size_t lds = 2ull * BKP * (BM + BN + 2 * PADE) * sizeof(T);
-    dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), (unsigned)nsplit);
+    dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), (unsigned)(nsplit * (n_items > 1 ? n_items : 1)));
     hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
@@ -1197,6 +1206,33 @@ extern "C" int cs_conv2d_wgrad_splits(const CsConvGeom* g, int grouped) {
     const bool wide = g->K > 64 && !grouped;
     const int cq = grouped ? 64 : g->C;
     return wgrad_splits((long long)g->N * g->P * g->Q, g->K, g->R * g->S * cq, wide ? 128 : 64);
+}
+
+extern "C" int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int n_items) {
+    if (!g || n_items < 1) return 0;
+    return wgrad_splits((long long)g->N * g->P * g->Q, g->K, g->R * g->S * g->C, g->K > 64 ? 128 : 64, n_items);
+}
+
+extern "C" int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
+                                       float* const* dw_tab, int n_items, int use_tr_read, void* stream) {
+    int rc = check_geom(g, dtype);
+    if (rc != CS_OK) return rc;
+    CS_CHECK_ARG(x_tab && dy_tab && dw_tab && n_items >= 1, "conv2d_wgrad_batched: bad tables");
+    WgradParams p{};
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    p.x_tab = x_tab; p.dy_tab = dy_tab; p.dw_tab = dw_tab;
+    p.H = g->H; p.W = g->W; p.C = g->C;
+    p.P = g->P; p.Q = g->Q; p.KO = g->K;
+    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
+    p.M = (long long)g->N * g->P * g->Q;
+    p.Cq = g->C; p.slab = 0;
+    p.QE = g->R * g->S * p.Cq;
+    p.SCc = g->C / ce;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool wide = g->K > 64;
+    if (dtype == CS_F32) return wide ? launch_wgrad<float, 128, 128, false>(p, st, n_items) : launch_wgrad<float, 64, 128, false>(p, st, n_items);
+    if (use_tr_read) return wide ? launch_wgrad<bf16_t, 128, 128, true>(p, st, n_items) : launch_wgrad<bf16_t, 64, 128, true>(p, st, n_items);
+    return wide ? launch_wgrad<bf16_t, 128, 128, false>(p, st, n_items) : launch_wgrad<bf16_t, 64, 128, false>(p, st, n_items);
 }
 
 extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,

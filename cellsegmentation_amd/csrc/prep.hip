@@ -329,6 +329,50 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
     return CS_OK;
 }
 
+// Batched form for n layers of identical geometry: one launch, blockIdx.z = layer.  Tables (device memory) hold, per layer:
+// raw slabs, w, scale, rstd, mean, gsum, dw, dgamma, dbeta, dot (any of the optional ones may be NULL for every layer alike).
+struct FinalizeTables {
+    const float* const* raw; const float* const* w; const float* const* scale; const float* const* rstd; const float* const* mean;
+    const float* const* gsum; float* const* dw; float* const* dgamma; float* const* dbeta; float* const* dot;
+};
+
+__global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit,
+                                                                       long long slab_stride, int want_dot) {
+    const int z = blockIdx.z, k = blockIdx.y;
+    const float* __restrict__ raw_p = t.raw[z];
+    const float* __restrict__ w = t.w[z];
+    const float sc = t.scale ? t.scale[z][k] : 1.f;
+    float* __restrict__ dw = t.dw[z];
+    const int per = Cin * RS;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.f;
+    if (i < per) {
+        const int rs = i / Cin, c = i - rs * Cin;
+        const long long src = ((long long)k * RS + rs) * Cp + c;
+        float raw = 0.f;
+        for (int s = 0; s < nsplit; ++s) raw += raw_p[s * slab_stride + src];
+        const long long o = (long long)k * per + c * RS + rs;
+        if (want_dot) contrib = w[o] * raw;
+        dw[o] = sc * raw;
+    }
+    if (want_dot) {
+        __shared__ float red[4];
+        contrib = wave_sum(contrib);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(t.dot[z] + k, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+__global__ void wgrad_finalize_b_batched_kernel(FinalizeTables t, int K) {
+    const int z = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float gs = t.gsum[z][k];
+    if (t.dgamma) t.dgamma[z][k] = t.rstd[z][k] * (t.dot[z][k] - t.mean[z][k] * gs);
+    if (t.dbeta) t.dbeta[z][k] = gs;
+}
+
 static int finalize_common(const float* raw, int nsplit, long long slab_stride, const float* w, const float* scale, const float* rstd,
                            const float* mean, const float* gsum, int K, int Cin, int RS, int Cp, int Cg_slab, float* dw, float* dbias,
                            float* dgamma, float* dbeta, float* dot_ws, int accumulate, hipStream_t st) {
@@ -420,5 +464,27 @@ extern "C" int cs_stage_conv_bn(const float* w, const float* gamma, const float*
     else
         CS_CHECK_ARG(false, "stage_conv_bn: bad dtype");
     CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_wgrad_finalize_batched(const float* const* tables /* device: 10 consecutive tables of n pointers */, int n_items,
+                                         int nsplit, int Kp, int K, int Cin, int R, int S, int Cp, int want_bn, void* stream) {
+    CS_CHECK_ARG(tables && n_items >= 1 && nsplit >= 1 && K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "wgrad_finalize_batched: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    FinalizeTables t;
+    auto tab = [&](int i) { return reinterpret_cast<const float* const*>(tables + (size_t)i * n_items); };
+    t.raw = tab(0); t.w = tab(1); t.scale = tab(2); t.rstd = tab(3); t.mean = tab(4); t.gsum = tab(5);
+    t.dw = (float* const*)(tables + (size_t)6 * n_items);
+    t.dgamma = want_bn ? (float* const*)(tables + (size_t)7 * n_items) : nullptr;
+    t.dbeta = want_bn ? (float* const*)(tables + (size_t)8 * n_items) : nullptr;
+    t.dot = (float* const*)(tables + (size_t)9 * n_items);
+    const int per = Cin * R * S;
+    hipLaunchKernelGGL(wgrad_finalize_a_batched_kernel, dim3((per + 255) / 256, K, n_items), dim3(256), 0, st, t, Cin, R * S, Cp, nsplit,
+                       (long long)Kp * R * S * Cp, want_bn);
+    CS_LAUNCH_CHECK();
+    if (want_bn) {
+        hipLaunchKernelGGL(wgrad_finalize_b_batched_kernel, dim3((K + 255) / 256, n_items), dim3(256), 0, st, t, K);
+        CS_LAUNCH_CHECK();
+    }
     return CS_OK;
 }

@@ -370,6 +370,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             raise NotImplementedError("engine: last contribution to a post-ReLU slot must come from a masking kernel")
         grads[slot] = g
 
+    deferred = {}
     for ui in reversed(range(len(plan.units))):
         u = plan.units[ui]
         g = grads.pop(u.dst, None)
@@ -398,7 +399,18 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                     pgrads[pindex[(ui, "gamma")]] = dgamma[:Kc]
                 if need(ui, "beta"):
                     pgrads[pindex[(ui, "beta")]] = dbeta[:Kc]
-            if want_w or want_b or (want_bn and not a.train):
+            defer = (want_w and want_bn and not want_b and not a.train and not u.grouped and u.bn is not None and conv.bias is None)
+            if defer:
+                # weight gradients of identical-geometry layers are launched together after the loop (one batched split-K
+                # launch per shape group: proportionally fewer partial slabs to write and fold)
+                gsum = gsum_cache.pop(u.dst, None)
+                if gsum is None:
+                    gsum = K.colsum(dz)
+                if u.res is not None and grads.get(u.res) is g:
+                    gsum_cache[u.res] = gsum
+                key = (geom.N, geom.H, geom.W, geom.C, geom.K, geom.R, geom.S, geom.stride, geom.pad)
+                deferred.setdefault(key, []).append(SimpleNamespace(ui=ui, u=u, a=a, x=x, dz=dz, gsum=gsum))
+            elif want_w or want_b or (want_bn and not a.train):
                 gsum = None
                 if want_b or (want_bn and not a.train):
                     gsum = gsum_cache.pop(u.dst, None) if not a.train else None
@@ -508,6 +520,31 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                     contribute(u.a, ga, masked=True)
                 if nb:
                     contribute(u.b, gb, masked=True)
+    for items in deferred.values():
+        geom = items[0].a.geom
+        n = len(items)
+        convs = [it.u.conv for it in items]
+        Kc, Cin = convs[0].out_channels, convs[0].in_channels
+        dws = [torch.empty_like(c.weight) for c in convs]
+        dgb = [torch.empty((2, Kc), dtype=torch.float32, device=dws[0].device) for _ in items]
+        dots = [take((Kc,)) for _ in items]
+        if n == 1:
+            it = items[0]
+            raw = K.new_wgrad_buffer(geom, it.x.device)
+            K.conv_wgrad(geom, it.x, it.dz, raw, use_tr_read=use_tr_read)
+            K.wgrad_finalize(raw, convs[0].weight.detach(), it.a.st.scale, it.a.st.rstd, it.u.bn.running_mean, it.gsum, Cin, dws[0],
+                             dgamma=dgb[0][0], dbeta=dgb[0][1], dot=dots[0])
+        else:
+            slabs, _tab = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
+            K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
+                                     [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
+                                     dws, [d[0] for d in dgb], [d[1] for d in dgb], dots, Cin)
+        for it, dw, d in zip(items, dws, dgb):
+            pgrads[pindex[(it.ui, "weight")]] = dw
+            if need(it.ui, "gamma"):
+                pgrads[pindex[(it.ui, "gamma")]] = d[0]
+            if need(it.ui, "beta"):
+                pgrads[pindex[(it.ui, "beta")]] = d[1]
     return {s: grads.get(s) for s in plan.inputs}, pgrads
 
 

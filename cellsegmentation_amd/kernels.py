@@ -123,7 +123,7 @@ class LaunchTimer:
 _timer = None
 
 
-def _timed(kind, geom, dtype, fn, extra_tensors=0):
+def _timed(kind, geom, dtype, fn, extra_tensors=0, batch=1):
     """extra_tensors: how many destination-shaped tensors the epilogue also reads (residual / add / mask)."""
     if _timer is None:
         return fn()
@@ -133,6 +133,7 @@ def _timed(kind, geom, dtype, fn, extra_tensors=0):
     e.record()
     g = {f: getattr(geom, f) for f, _ in geom._fields_}
     g["extra"] = extra_tensors
+    g["batch"] = batch
     _timer.records.append((kind, g, dtype, s, e))
     return rc
 
@@ -216,6 +217,41 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
     _lib.check(_timed("wgrad", geom, x.dtype, lambda: lib.cs_conv2d_wgrad(
         ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw_raw), 1 if use_tr_read else 0, _stream())), "conv2d_wgrad")
     return dw_raw
+
+
+def wgrad_batched(geom, xs, dys, use_tr_read=True):
+    """Batched wgrad over len(xs) layers of identical geometry.  Returns the list of split-K slab buffers."""
+    n = len(xs)
+    lib = _lib.load()
+    nsplit = lib.cs_conv2d_wgrad_batched_splits(ctypes.byref(geom), n)
+    dev = xs[0].device
+    slabs = torch.empty((n, nsplit, geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=dev)
+    for t in list(xs) + list(dys):
+        _p(t)                                  # device / contiguity checks
+    table = torch.tensor([t.data_ptr() for t in xs] + [t.data_ptr() for t in dys] + [slabs[i].data_ptr() for i in range(n)],
+                         dtype=torch.int64, device=dev)
+    base = table.data_ptr()
+    _lib.check(_timed("wgrad", geom, xs[0].dtype, lambda: lib.cs_conv2d_wgrad_batched(
+        ctypes.byref(geom), _code(xs[0].dtype), ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * n), ctypes.c_void_p(base + 16 * n), n,
+        1 if use_tr_read else 0, _stream()), batch=n), "conv2d_wgrad_batched")
+    return slabs, table
+
+
+def wgrad_finalize_batched(slabs, ws, scales, rstds, means, gsums, dws, dgammas, dbetas, dots, Cin):
+    """Batched finalize for the eval-BN trunk: lists of n tensors each (scales..gsums/dgammas/dbetas None-lists when no BN)."""
+    n, nsplit, Kp, R, S, Cp = slabs.shape
+    K_ = dws[0].shape[0]
+    want_bn = dgammas is not None
+    dev = slabs.device
+
+    def ptrs(lst):
+        return [0] * n if lst is None else [t.data_ptr() for t in lst]
+
+    table = torch.tensor([slabs[i].data_ptr() for i in range(n)] + ptrs(ws) + ptrs(scales) + ptrs(rstds) + ptrs(means) + ptrs(gsums) +
+                         ptrs(dws) + ptrs(dgammas) + ptrs(dbetas) + ptrs(dots), dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().cs_wgrad_finalize_batched(ctypes.c_void_p(table.data_ptr()), n, nsplit, Kp, K_, Cin, R, S, Cp,
+                                                     1 if want_bn else 0, _stream()), "wgrad_finalize_batched")
+    return table
 
 
 def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False, dot=None):

@@ -122,6 +122,18 @@ int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* 
 int cs_conv2d_wgrad_splits(const CsConvGeom* g, int grouped);
 int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                     int use_tr_read, void* stream);
+/* Batched weight gradient for n_items layers of IDENTICAL geometry (the repeated blocks of a ResNet stage): one launch,
+ * blockIdx.z = item*nsplit + slice, nsplit = cs_conv2d_wgrad_batched_splits(g, n_items) (fewer slices per layer ->
+ * proportionally less partial-slab traffic).  x_tab / dy_tab / dw_tab: DEVICE arrays of n_items pointers; dw_tab[i] is a
+ * [nsplit][K][R][S][Cp] fp32 buffer. */
+int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int n_items);
+int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
+                            float* const* dw_tab, int n_items, int use_tr_read, void* stream);
+/* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped): `tables` = DEVICE array of 10*n_items pointers:
+ * [raw | w | scale | rstd | mean | gsum | dw | dgamma | dbeta | dot] x n_items (scale..gsum, dgamma, dbeta used only with
+ * want_bn; dot zeroed by the caller). */
+int cs_wgrad_finalize_batched(const float* const* tables, int n_items, int nsplit, int Kp, int K, int Cin, int R, int S, int Cp,
+                              int want_bn, void* stream);
 /* dw[K][Cin][R][S] (torch layout, ACCUMULATED into when accumulate!=0) = scale[k]*dw_khwc[k][r][s][c];
  * dbias[k] = scale[k]*gsum[k] (conv bias); and, when dgamma/dbeta non-NULL, the eval-mode BatchNorm parameter gradients
  *   dbeta[k] = gsum[k];  dgamma[k] = rstd[k]*( sum_j w[k][j]*dw_raw[k][j] - mean[k]*gsum[k] ). */
