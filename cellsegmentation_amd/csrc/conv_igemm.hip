@@ -944,10 +944,12 @@ struct WgradParams {
     int SCc;          // C / chunk
     long long m_per_split;   // multiple of the K-step
     long long slab_stride;   // elements between split-K slabs (KO*QE)
-    // batched launch over n identical-geometry layers: blockIdx.z = item * nsplit + slice; tables live in device memory
-    const void* const* x_tab;
-    const void* const* dy_tab;
-    float* const* dw_tab;
+    // batched launch over n <= 8 identical-geometry layers: blockIdx.z = item * nsplit + slice; the pointer tables travel BY VALUE
+    // in the kernel arguments (a device-memory table would need a blocking host-to-device copy every step)
+    const void* x_tab[8];
+    const void* dy_tab[8];
+    float* dw_tab[8];
+    int n_items;
     int nsplit;
 };
 
@@ -978,16 +980,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
     const int k0 = blockIdx.x * BM;          // output-channel tile origin
     const int q0 = blockIdx.y * BN;          // K-space (tap,c) element origin
-    const int item = p.x_tab ? (int)(blockIdx.z / p.nsplit) : 0;
-    const int slice = p.x_tab ? (int)(blockIdx.z % p.nsplit) : (int)blockIdx.z;
+    const int item = p.n_items ? (int)(blockIdx.z / p.nsplit) : 0;
+    const int slice = p.n_items ? (int)(blockIdx.z % p.nsplit) : (int)blockIdx.z;
     const long long mbeg = (long long)slice * p.m_per_split;
     long long mend = mbeg + p.m_per_split;
     if (mend > p.M) mend = p.M;
     // (slices are non-empty by construction: nsplit = ceil(M / m_per_split); an empty one would still write zeros)
 
-    const T* __restrict__ xs = reinterpret_cast<const T*>(p.x_tab ? p.x_tab[item] : p.x);
-    const T* __restrict__ gs = reinterpret_cast<const T*>(p.x_tab ? p.dy_tab[item] : p.dy);
-    float* __restrict__ dw_base = p.x_tab ? p.dw_tab[item] : p.dw;
+    const T* __restrict__ xs = reinterpret_cast<const T*>(p.n_items ? p.x_tab[item] : p.x);
+    const T* __restrict__ gs = reinterpret_cast<const T*>(p.n_items ? p.dy_tab[item] : p.dy);
+    float* __restrict__ dw_base = p.n_items ? p.dw_tab[item] : p.dw;
 
     // A operand (dy): chunk column fixed per thread
     const int ac = tid % ACPR;
@@ -1217,10 +1219,11 @@ extern "C" int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const voi
                                        float* const* dw_tab, int n_items, int use_tr_read, void* stream) {
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
-    CS_CHECK_ARG(x_tab && dy_tab && dw_tab && n_items >= 1, "conv2d_wgrad_batched: bad tables");
+    CS_CHECK_ARG(x_tab && dy_tab && dw_tab && n_items >= 1 && n_items <= 8, "conv2d_wgrad_batched: 1..8 items, HOST pointer arrays");
     WgradParams p{};
     const int ce = dtype == CS_F32 ? 4 : 8;
-    p.x_tab = x_tab; p.dy_tab = dy_tab; p.dw_tab = dw_tab;
+    for (int i = 0; i < n_items; ++i) { p.x_tab[i] = x_tab[i]; p.dy_tab[i] = dy_tab[i]; p.dw_tab[i] = dw_tab[i]; }
+    p.n_items = n_items;
     p.H = g->H; p.W = g->W; p.C = g->C;
     p.P = g->P; p.Q = g->Q; p.KO = g->K;
     p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;

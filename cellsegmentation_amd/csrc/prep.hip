@@ -331,9 +331,10 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
 
 // Batched form for n layers of identical geometry: one launch, blockIdx.z = layer.  Tables (device memory) hold, per layer:
 // raw slabs, w, scale, rstd, mean, gsum, dw, dgamma, dbeta, dot (any of the optional ones may be NULL for every layer alike).
-struct FinalizeTables {
-    const float* const* raw; const float* const* w; const float* const* scale; const float* const* rstd; const float* const* mean;
-    const float* const* gsum; float* const* dw; float* const* dgamma; float* const* dbeta; float* const* dot;
+struct FinalizeTables {      // by value in the kernel arguments, n <= 8 layers
+    const float* raw[8]; const float* w[8]; const float* scale[8]; const float* rstd[8]; const float* mean[8];
+    const float* gsum[8]; float* dw[8]; float* dgamma[8]; float* dbeta[8]; float* dot[8];
+    int has_scale, want_bn;
 };
 
 __global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit,
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeT
     const int z = blockIdx.z, k = blockIdx.y;
     const float* __restrict__ raw_p = t.raw[z];
     const float* __restrict__ w = t.w[z];
-    const float sc = t.scale ? t.scale[z][k] : 1.f;
+    const float sc = t.has_scale ? t.scale[z][k] : 1.f;
     float* __restrict__ dw = t.dw[z];
     const int per = Cin * RS;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,8 +370,8 @@ __global__ void wgrad_finalize_b_batched_kernel(FinalizeTables t, int K) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const float gs = t.gsum[z][k];
-    if (t.dgamma) t.dgamma[z][k] = t.rstd[z][k] * (t.dot[z][k] - t.mean[z][k] * gs);
-    if (t.dbeta) t.dbeta[z][k] = gs;
+    t.dgamma[z][k] = t.rstd[z][k] * (t.dot[z][k] - t.mean[z][k] * gs);
+    t.dbeta[z][k] = gs;
 }
 
 static int finalize_common(const float* raw, int nsplit, long long slab_stride, const float* w, const float* scale, const float* rstd,
@@ -467,17 +468,20 @@ extern "C" int cs_stage_conv_bn(const float* w, const float* gamma, const float*
     return CS_OK;
 }
 
-extern "C" int cs_wgrad_finalize_batched(const float* const* tables /* device: 10 consecutive tables of n pointers */, int n_items,
+extern "C" int cs_wgrad_finalize_batched(const float* const* tables /* HOST: 10 consecutive tables of n pointers */, int n_items,
                                          int nsplit, int Kp, int K, int Cin, int R, int S, int Cp, int want_bn, void* stream) {
-    CS_CHECK_ARG(tables && n_items >= 1 && nsplit >= 1 && K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K, "wgrad_finalize_batched: bad arguments");
+    CS_CHECK_ARG(tables && n_items >= 1 && n_items <= 8 && nsplit >= 1 && K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K,
+                 "wgrad_finalize_batched: bad arguments (1..8 items, HOST pointer tables)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    FinalizeTables t;
-    auto tab = [&](int i) { return reinterpret_cast<const float* const*>(tables + (size_t)i * n_items); };
-    t.raw = tab(0); t.w = tab(1); t.scale = tab(2); t.rstd = tab(3); t.mean = tab(4); t.gsum = tab(5);
-    t.dw = (float* const*)(tables + (size_t)6 * n_items);
-    t.dgamma = want_bn ? (float* const*)(tables + (size_t)7 * n_items) : nullptr;
-    t.dbeta = want_bn ? (float* const*)(tables + (size_t)8 * n_items) : nullptr;
-    t.dot = (float* const*)(tables + (size_t)9 * n_items);
+    FinalizeTables t{};
+    for (int i = 0; i < n_items; ++i) {
+        t.raw[i] = tables[0 * n_items + i]; t.w[i] = tables[1 * n_items + i]; t.scale[i] = tables[2 * n_items + i];
+        t.rstd[i] = tables[3 * n_items + i]; t.mean[i] = tables[4 * n_items + i]; t.gsum[i] = tables[5 * n_items + i];
+        t.dw[i] = const_cast<float*>(tables[6 * n_items + i]); t.dgamma[i] = const_cast<float*>(tables[7 * n_items + i]);
+        t.dbeta[i] = const_cast<float*>(tables[8 * n_items + i]); t.dot[i] = const_cast<float*>(tables[9 * n_items + i]);
+    }
+    t.has_scale = tables[2 * n_items] != nullptr;
+    t.want_bn = want_bn;
     const int per = Cin * R * S;
     hipLaunchKernelGGL(wgrad_finalize_a_batched_kernel, dim3((per + 255) / 256, K, n_items), dim3(256), 0, st, t, Cin, R * S, Cp, nsplit,
                        (long long)Kp * R * S * Cp, want_bn);

@@ -520,7 +520,10 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                     contribute(u.a, ga, masked=True)
                 if nb:
                     contribute(u.b, gb, masked=True)
+    chunks = []
     for items in deferred.values():
+        chunks += [items[i:i + 8] for i in range(0, len(items), 8)]       # kernel-argument tables hold at most 8 layers
+    for items in chunks:
         geom = items[0].a.geom
         n = len(items)
         convs = [it.u.conv for it in items]
@@ -535,7 +538,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             K.wgrad_finalize(raw, convs[0].weight.detach(), it.a.st.scale, it.a.st.rstd, it.u.bn.running_mean, it.gsum, Cin, dws[0],
                              dgamma=dgb[0][0], dbeta=dgb[0][1], dot=dots[0])
         else:
-            slabs, _tab = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
+            slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
             K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
                                      [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
                                      dws, [d[0] for d in dgb], [d[1] for d in dgb], dots, Cin)

@@ -220,38 +220,34 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
 
 
 def wgrad_batched(geom, xs, dys, use_tr_read=True):
-    """Batched wgrad over len(xs) layers of identical geometry.  Returns the list of split-K slab buffers."""
+    """Batched wgrad over len(xs) <= 8 layers of identical geometry.  Returns the split-K slab buffer [n, nsplit, K, R, S, Cp]."""
     n = len(xs)
     lib = _lib.load()
     nsplit = lib.cs_conv2d_wgrad_batched_splits(ctypes.byref(geom), n)
-    dev = xs[0].device
-    slabs = torch.empty((n, nsplit, geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=dev)
+    slabs = torch.empty((n, nsplit, geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=xs[0].device)
     for t in list(xs) + list(dys):
         _p(t)                                  # device / contiguity checks
-    table = torch.tensor([t.data_ptr() for t in xs] + [t.data_ptr() for t in dys] + [slabs[i].data_ptr() for i in range(n)],
-                         dtype=torch.int64, device=dev)
-    base = table.data_ptr()
+    arr = ctypes.c_void_p * n
+    xt, dt_, wt = arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dys]), arr(*[slabs[i].data_ptr() for i in range(n)])
     _lib.check(_timed("wgrad", geom, xs[0].dtype, lambda: lib.cs_conv2d_wgrad_batched(
-        ctypes.byref(geom), _code(xs[0].dtype), ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * n), ctypes.c_void_p(base + 16 * n), n,
-        1 if use_tr_read else 0, _stream()), batch=n), "conv2d_wgrad_batched")
-    return slabs, table
+        ctypes.byref(geom), _code(xs[0].dtype), xt, dt_, wt, n, 1 if use_tr_read else 0, _stream()), batch=n), "conv2d_wgrad_batched")
+    return slabs
 
 
 def wgrad_finalize_batched(slabs, ws, scales, rstds, means, gsums, dws, dgammas, dbetas, dots, Cin):
-    """Batched finalize for the eval-BN trunk: lists of n tensors each (scales..gsums/dgammas/dbetas None-lists when no BN)."""
+    """Batched finalize for the eval-BN trunk: lists of n <= 8 tensors each."""
     n, nsplit, Kp, R, S, Cp = slabs.shape
     K_ = dws[0].shape[0]
     want_bn = dgammas is not None
-    dev = slabs.device
 
     def ptrs(lst):
-        return [0] * n if lst is None else [t.data_ptr() for t in lst]
+        return [None] * n if lst is None else [t.data_ptr() for t in lst]
 
-    table = torch.tensor([slabs[i].data_ptr() for i in range(n)] + ptrs(ws) + ptrs(scales) + ptrs(rstds) + ptrs(means) + ptrs(gsums) +
-                         ptrs(dws) + ptrs(dgammas) + ptrs(dbetas) + ptrs(dots), dtype=torch.int64, device=dev)
-    _lib.check(_lib.load().cs_wgrad_finalize_batched(ctypes.c_void_p(table.data_ptr()), n, nsplit, Kp, K_, Cin, R, S, Cp,
-                                                     1 if want_bn else 0, _stream()), "wgrad_finalize_batched")
-    return table
+    flat = [slabs[i].data_ptr() for i in range(n)] + ptrs(ws) + ptrs(scales) + ptrs(rstds) + ptrs(means) + ptrs(gsums) + ptrs(dws) + \
+        ptrs(dgammas) + ptrs(dbetas) + ptrs(dots)
+    table = (ctypes.c_void_p * len(flat))(*flat)
+    _lib.check(_lib.load().cs_wgrad_finalize_batched(table, n, nsplit, Kp, K_, Cin, R, S, Cp, 1 if want_bn else 0, _stream()),
+               "wgrad_finalize_batched")
 
 
 def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False, dot=None):

@@ -124,12 +124,12 @@ int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* d
                     int use_tr_read, void* stream);
 /* Batched weight gradient for n_items layers of IDENTICAL geometry (the repeated blocks of a ResNet stage): one launch,
  * blockIdx.z = item*nsplit + slice, nsplit = cs_conv2d_wgrad_batched_splits(g, n_items) (fewer slices per layer ->
- * proportionally less partial-slab traffic).  x_tab / dy_tab / dw_tab: DEVICE arrays of n_items pointers; dw_tab[i] is a
- * [nsplit][K][R][S][Cp] fp32 buffer. */
+ * proportionally less partial-slab traffic).  x_tab / dy_tab / dw_tab: HOST arrays of n_items (<= 8) device pointers (they
+ * are passed to the kernel by value, no device table, no copy); dw_tab[i] is a [nsplit][K][R][S][Cp] fp32 buffer. */
 int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int n_items);
 int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
                             float* const* dw_tab, int n_items, int use_tr_read, void* stream);
-/* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped): `tables` = DEVICE array of 10*n_items pointers:
+/* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped): `tables` = HOST array of 10*n_items (n <= 8) pointers:
  * [raw | w | scale | rstd | mean | gsum | dw | dgamma | dbeta | dot] x n_items (scale..gsum, dgamma, dbeta used only with
  * want_bn; dot zeroed by the caller). */
 int cs_wgrad_finalize_batched(const float* const* tables, int n_items, int nsplit, int Kp, int K, int Cin, int R, int S, int Cp,
