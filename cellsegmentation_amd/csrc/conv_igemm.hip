@@ -987,9 +987,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     if (mend > p.M) mend = p.M;
     // (slices are non-empty by construction: nsplit = ceil(M / m_per_split); an empty one would still write zeros)
 
-    const T* __restrict__ xs = reinterpret_cast<const T*>(p.n_items ? p.x_tab[item] : p.x);
-    const T* __restrict__ gs = reinterpret_cast<const T*>(p.n_items ? p.dy_tab[item] : p.dy);
-    float* __restrict__ dw_base = p.n_items ? p.dw_tab[item] : p.dw;
+    // static indices only: a runtime index into a by-value argument array would push the whole struct to scratch
+    const void* xsel = p.x;
+    const void* gsel = p.dy;
+    float* dsel = p.dw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (p.n_items && item == i) { xsel = p.x_tab[i]; gsel = p.dy_tab[i]; dsel = p.dw_tab[i]; }
+    const T* __restrict__ xs = reinterpret_cast<const T*>(xsel);
+    const T* __restrict__ gs = reinterpret_cast<const T*>(gsel);
+    float* __restrict__ dw_base = dsel;
 
     // A operand (dy): chunk column fixed per thread
     const int ac = tid % ACPR;

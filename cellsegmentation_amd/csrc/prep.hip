@@ -340,10 +340,15 @@ struct FinalizeTables {      // by value in the kernel arguments, n <= 8 layers
 __global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit,
                                                                        long long slab_stride, int want_dot) {
     const int z = blockIdx.z, k = blockIdx.y;
-    const float* __restrict__ raw_p = t.raw[z];
-    const float* __restrict__ w = t.w[z];
-    const float sc = t.has_scale ? t.scale[z][k] : 1.f;
-    float* __restrict__ dw = t.dw[z];
+    // static indices only (a runtime index into the by-value tables would spill them to scratch)
+    const float* raw_s = nullptr; const float* w_s = nullptr; const float* sc_s = nullptr; float* dw_s = nullptr; float* dot_s = nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (z == i) { raw_s = t.raw[i]; w_s = t.w[i]; sc_s = t.scale[i]; dw_s = t.dw[i]; dot_s = t.dot[i]; }
+    const float* __restrict__ raw_p = raw_s;
+    const float* __restrict__ w = w_s;
+    const float sc = t.has_scale ? sc_s[k] : 1.f;
+    float* __restrict__ dw = dw_s;
     const int per = Cin * RS;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float contrib = 0.f;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeT
         contrib = wave_sum(contrib);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(t.dot[z] + k, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) atomicAdd(dot_s + k, red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -369,9 +374,14 @@ __global__ void wgrad_finalize_b_batched_kernel(FinalizeTables t, int K) {
     const int z = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    const float gs = t.gsum[z][k];
-    t.dgamma[z][k] = t.rstd[z][k] * (t.dot[z][k] - t.mean[z][k] * gs);
-    t.dbeta[z][k] = gs;
+    const float* gsum = nullptr; const float* rstd = nullptr; const float* mean = nullptr; const float* dot = nullptr;
+    float* dgamma = nullptr; float* dbeta = nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (z == i) { gsum = t.gsum[i]; rstd = t.rstd[i]; mean = t.mean[i]; dot = t.dot[i]; dgamma = t.dgamma[i]; dbeta = t.dbeta[i]; }
+    const float gs = gsum[k];
+    dgamma[k] = rstd[k] * (dot[k] - mean[k] * gs);
+    dbeta[k] = gs;
 }
 
 static int finalize_common(const float* raw, int nsplit, long long slab_stride, const float* w, const float* scale, const float* rstd,
