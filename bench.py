@@ -212,7 +212,9 @@ def main():
 
     model = build_model(dev, dtype)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4)
+    # same torch.optim.Adam the reference constructs (train_tile.py:282); fused=True is torch's single-launch
+    # multi-tensor implementation of that update (the default foreach path is ~15 launches and 0.7 ms per step)
+    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4, fused=dev.type == "cuda")
     reducer = GradReducer(params) if world > 1 else None
     if reducer is not None:
         reducer.broadcast_parameters(model)

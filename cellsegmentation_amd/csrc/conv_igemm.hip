@@ -32,7 +32,7 @@ struct IgemmParams {
     const float* shift;
     const void* residual;
     const void* mask;
-    float* slab;      // nullable fp32 [gridDim.x][2][NOUT]: per-workgroup column sums / sums of squares of the
+    float* slab;      // nullable fp32 [M tiles][2][NOUT]: per-workgroup column sums / sums of squares of the
                       // stored output (no atomics; cs_slab_reduce folds the rows afterwards)
     int SH, SW, SC;   // source extents, stored channels
     int DH, DW;       // destination spatial extents
@@ -222,8 +222,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (1-D grid): workgroup ids go round-robin over the 8 XCDs, so id = 8*slot + xcd.  All N tiles of
+    // one M tile run back-to-back on ONE XCD: the second N tile finds the source rows in that XCD's L2 and the two
+    // half-row output writes meet there before they go to HBM.
+    const int n_ntiles = (p.NOUT + BN - 1) / BN;
+    const unsigned slot = blockIdx.x >> 3;
+    const long long mtile = (long long)(slot / n_ntiles) * 8 + (blockIdx.x & 7);
+    const long long m0 = mtile * BM;
+    const int n0 = (int)(slot % n_ntiles) * BN;
+    if (m0 >= p.M) return;     // grid is padded to 8 M tiles per round
 
     // ---- per-thread gather bookkeeping: fixed rows, walking (kh,kw,cc) ----
     const int lc = tid & 7;    // chunk column inside the K-step
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, blockIdx.x);
+    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, mtile);
 }
 
 
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 //  * needs every operand < 2 GiB (32-bit buffer offsets); larger tensors use the register path.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
+__global__ __launch_bounds__(256, 4) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int ES = (int)sizeof(T);
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AI = BM / 32, BI = BN / 32;
@@ -413,8 +420,15 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (1-D grid): workgroup ids go round-robin over the 8 XCDs, so id = 8*slot + xcd.  All N tiles of
+    // one M tile run back-to-back on ONE XCD: the second N tile finds the source rows in that XCD's L2 and the two
+    // half-row output writes meet there before they go to HBM.
+    const int n_ntiles = (p.NOUT + BN - 1) / BN;
+    const unsigned slot = blockIdx.x >> 3;
+    const long long mtile = (long long)(slot / n_ntiles) * 8 + (blockIdx.x & 7);
+    const long long m0 = mtile * BM;
+    const int n0 = (int)(slot % n_ntiles) * BN;
+    if (m0 >= p.M) return;     // grid is padded to 8 M tiles per round
 
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, wgt_bytes, 0x00020000);
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams p, unsigned 
         }
     }
     __syncthreads();
-    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, blockIdx.x);
+    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, mtile);
 }
 
 
@@ -705,7 +719,8 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     size_t lds = (nk_host <= 1 ? 1 : 2) * one_stage;           // a single K-step needs a single stage
     if (lds < epi_bytes) lds = epi_bytes;
     if (lds < red_bytes) lds = red_bytes;
-    dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.NOUT + BN - 1) / BN), 1);
+    const unsigned n_mt = (unsigned)((p.M + BM - 1) / BM), n_nt = (unsigned)((p.NOUT + BN - 1) / BN);
+    dim3 grid(((n_mt + 7) / 8) * 8 * n_nt, 1, 1);             // see the tile-order note in the kernels
     const unsigned long long src_bytes = (unsigned long long)p.src_pixels * p.SC * sizeof(T);
     const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.wrow_chunks * 16ull;
     const bool dma = g_igemm_path == 0 && src_bytes < 0x80000000ull && wgt_bytes < 0x80000000ull;

@@ -37,3 +37,7 @@ timeit("cs bn_apply +res (2r+w)", lambda: K.bn_apply(x, mean, rstd, g, b, x, K.C
 timeit("cs colsum (r)", lambda: K.colsum(x), nbytes)
 x64 = torch.randn((N, 150, 150, 64), device=dev).to(torch.bfloat16)
 timeit("cs maxpool fwd (r + w/4 + idx)", lambda: K.maxpool_fwd(x64), x64.numel() * 2 * 1.25 + x64.numel() / 4)
+timeit("torch fill_ (w)", lambda: y.zero_(), nbytes)
+timeit("torch sum (r)", lambda: x.sum(), nbytes)
+x4 = torch.randn((N, H, W, 64), device=dev).to(torch.bfloat16)
+timeit("torch repeat 1->4 (r/4 + w)", lambda: torch.cat([x4, x4, x4, x4], dim=-1, out=y), 1.25 * nbytes)
