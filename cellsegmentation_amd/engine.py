@@ -175,12 +175,17 @@ def _bn_uses_batch_stats(bn, bn_train):
     return bn is not None and bn_train and bn.training
 
 
-def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded):
-    """BN folding + weight staging, cached while the parameters are unchanged (frozen encoders)."""
+def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded, training):
+    """BN folding + weight staging.  Cached only for frozen parameters and for no-grad passes: a forward that will
+    be followed by an optimizer step (`training` and the parameter requires grad) always stages afresh and leaves the
+    cache invalid, because tensor version counters cannot be trusted to see the update -- torch's fused optimizers
+    (`Adam(fused=True)`) write the parameters without bumping `_version`."""
     conv, bn = u.conv, u.bn
     key_t = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
     key = (dtype, Cp, Kp, need_bwd, folded) + tuple((t._version, t.data_ptr()) if t is not None else None for t in key_t)
-    if u._cache is not None and u._cache[0] == key:
+    if training and any(t is not None and t.requires_grad for t in key_t):
+        key = None
+    elif u._cache is not None and u._cache[0] == key:
         return u._cache[1]
     w = conv.weight.detach()
     bias = conv.bias.detach() if conv.bias is not None else None
@@ -232,7 +237,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             res = t[u.res] if u.res is not None else None
             need_bwd = save and requires.get(u.src, False)
             batch_stats = _bn_uses_batch_stats(u.bn, bn_train)
-            st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats)
+            st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save)
             if not batch_stats:
                 y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=False)

@@ -149,3 +149,31 @@ def test_loss_modules_match_reference_vectors(dev):
     assert float((p.grad.cpu() - pc.grad).abs().max()) < 1e-6
     d = T.dice_coef(a, b)
     assert float((d.cpu() - orc.dice_coef(a.cpu(), b.cpu())).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_staged_weights_follow_the_optimizer(dev, fused):
+    """The folded/staged weight cache must never outlive a parameter update.  torch's fused optimizers write the
+    parameters without bumping `_version`, so a version-keyed cache alone would keep serving the old weights."""
+    x = synth.normalise(synth.ihc_tiles(8, 32, 77)).to(dev)
+    y = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1], device=dev)
+    m = _model("resnet18", dev)
+    m.setmode("tile")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=fused)
+    m.eval()
+    with torch.no_grad():
+        before = m(x).clone()              # fills the cache
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        opt.step()
+    with torch.no_grad():
+        after = m(x).clone()
+    fresh = _model("resnet18", dev)        # same architecture, empty cache, the trained parameters
+    fresh.load_state_dict(m.state_dict())
+    fresh.setmode("tile")
+    fresh.eval()
+    with torch.no_grad():
+        expect = fresh(x)
+    assert float((after - before).abs().max()) > 1e-3          # the update is visible at all
+    assert torch.equal(after, expect)

@@ -3,9 +3,13 @@
 
 usage: python tools/kernel_resources.py cellsegmentation_amd/csrc/conv_igemm.hip [name-filter]
 """
+import os
 import re
 import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_profile import demangle  # noqa: E402  (knows the bf16 vendor type c++filt does not)
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -20,9 +24,7 @@ for line in out.splitlines():
     body = m.group(1)
     if body.startswith("Function Name:"):
         name = body.split(":", 1)[1].strip()
-        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-        dem = re.sub(r"\(anonymous namespace\)::", "", dem)
-        dem = re.sub(r"\(.*$", "", dem).replace("void ", "")
+        dem = demangle(name)
         cur = {"name": dem}
         rows.append(cur)
     elif cur is not None and ":" in body:
