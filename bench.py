@@ -144,6 +144,23 @@ def roofline_from(records, steps, dtype):
             "by_family": {k: row(v, True) for k, v in sorted(per_family.items())}}
 
 
+def per_layer_table(records, steps, dtype):
+    """One line per (kind, geometry): launches/step, average time, algorithmic GB/s and TFLOP/s (stderr, --per-layer)."""
+    es = 2 if dtype == torch.bfloat16 else 4
+    rows = {}
+    for kind, g, dt, ms in records:
+        key = (kind, g["R"], g["stride"], g["C"], g["K"], g["H"], g["extra"], g.get("batch", 1))
+        e = rows.setdefault(key, [0.0, 0, conv_flops(g), conv_bytes(kind, g, es), kernel_name(kind, g, dt)])
+        e[0] += ms; e[1] += 1
+    out = [f"{'kind':6s} {'RxR/s':6s} {'C':>5s} {'K':>5s} {'H':>4s} {'ex':>2s} {'b':>2s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'GB/s':>7s} {'TF/s':>7s}  kernel"]
+    for key, (ms, n, fl, by, name) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+        kind, R, st, C, Kc, H, ex, b = key
+        avg = ms / n
+        out.append(f"{kind:6s} {R}x{R}/{st:<2d} {C:5d} {Kc:5d} {H:4d} {ex:2d} {b:2d} {n / steps:6.1f} {avg * 1e3:8.1f} {ms / steps:8.3f} "
+                   f"{by / (avg * 1e-3) / 1e9:7.0f} {fl / (avg * 1e-3) / 1e12:7.1f}  {name}")
+    return "\n".join(out)
+
+
 def cpu_baseline(sample_tiles=8, steps=2):
     """The oracle (torch CPU fp32 NCHW, proven equal to the reference in tests/golden/make_golden.py)
     on the same step definition, bounded sample."""
@@ -187,6 +204,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
+    ap.add_argument("--per-layer", action="store_true", help="also print a per-geometry launch table to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -266,6 +284,8 @@ def main():
     if rank == 0:
         final_loss = float(loss_acc.item()) / max(1, args.steps + args.warmup)
         roof = roofline_from(timer.results(), args.steps, dtype) if timer is not None else None
+        if timer is not None and args.per_layer:
+            print(per_layer_table(timer.results(), args.steps, dtype), file=sys.stderr)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()

@@ -74,9 +74,44 @@ template <> struct Mma<float> {
     }
 };
 
+// Epilogue operands (residual / add, mask) of one thread, fetched BEFORE the K loop so their latency hides behind it
+// (bf16 only: one 16-byte chunk = the thread's 8 channels).  Same row / channel-group ownership as igemm_epilogue.
+template <int BM, int BN> struct EpiRegs {
+    static constexpr int ITERS = (BM / 2) * BN / 8 / 256;
+    uint4 res[2 * ITERS];
+    uint4 msk[2 * ITERS];
+};
+
 template <typename T, int BM, int BN>
+__device__ __forceinline__ void epi_prefetch(const IgemmParams& p, long long m0, int n0, EpiRegs<BM, BN>& e) {
+    static_assert(sizeof(T) == 2, "epilogue prefetch is a bf16 path");
+    constexpr int CG = BN / 8, HROWS = BM / 2, ITERS = EpiRegs<BM, BN>::ITERS;
+    const int tid = threadIdx.x;
+    const int o = n0 + (tid % CG) * 8;
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    const T* __restrict__ msk = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const long long m = m0 + half * HROWS + it * (256 / CG) + tid / CG;
+            const bool ok = m < p.M && o < p.NOUT;
+            const long long off = m * p.NOUT + o;          // identity row -> pixel mapping only (dst_step == 1)
+            e.res[half * ITERS + it] = (res && ok) ? *reinterpret_cast<const uint4*>(res + off) : make_uint4(0, 0, 0, 0);
+            e.msk[half * ITERS + it] = (msk && ok) ? *reinterpret_cast<const uint4*>(msk + off) : make_uint4(0, 0, 0, 0);
+        }
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4& a, float (&v)[8]) {
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+
+template <typename T, int BM, int BN, bool PF = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* smem_raw,
-                                               long long m0, int n0, long long slab_row) {
+                                               long long m0, int n0, long long slab_row, const EpiRegs<BM, BN>* pf = nullptr) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,7 +187,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 }
                 if (res) {
                     float r8[8];
-                    load8<T>(res + off, r8);
+                    if constexpr (PF) unpack_bf16x8(pf->res[half * ITERS + it], r8);
+                    else load8<T>(res + off, r8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r8[e];
                 }
@@ -165,7 +201,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 }
                 if (msk) {
                     float k8[8];
-                    load8<T>(msk + off, k8);
+                    if constexpr (PF) unpack_bf16x8(pf->msk[half * ITERS + it], k8);
+                    else load8<T>(msk + off, k8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
                 }
@@ -404,8 +441,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 //    hardware range check returns zeros, which the DMA writes to LDS -- no branches, no masks;
 //  * needs every operand < 2 GiB (32-bit buffer offsets); larger tensors use the register path.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 4) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
+//  * PF (bf16, > 1 K-step, identity destination mapping): the residual / mask operands of the epilogue are fetched into
+//    registers before the K loop.  Multi-K-step launches hold 2 LDS stages = 2 workgroups per CU, so the register budget
+//    is 256 per wave anyway; without this the fat epilogue of the wide-output layers (2 operand reads + 1 write per
+//    output element) ran strictly after the K loop with nothing else in flight.
+template <typename T, int BM, int BN, int MODE, bool PF = false>
+__global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int ES = (int)sizeof(T);
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AI = BM / 32, BI = BN / 32;
@@ -547,12 +588,18 @@ __global__ __launch_bounds__(256, 4) void igemm_dma_kernel(IgemmParams p, unsign
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    EpiRegs<BM, BN> er;
+    if constexpr (PF) epi_prefetch<T, BM, BN>(p, m0, n0, er);
     const int nk = (p.Qtot + 7) / 8;
+    // both stages are requested up front (vmcnt retires in issue order: AI+BI outstanding = stage 0 has landed), then
+    // stage ks+1 is re-requested into the buffer iteration ks-1 has finished reading
     issue(0);
+    if (nk > 1) issue(1);
     for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile ks have landed
+        if (ks == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile ks have landed
         __syncthreads();                                    // ... and everybody else's; also frees the other buffer
-        if (ks + 1 < nk) issue((ks + 1) & 1);
+        if (ks >= 1 && ks + 1 < nk) issue((ks + 1) & 1);
         const uint4* As = smem + (ks & 1) * STAGE;
         const uint4* Bs = As + BM * 8;
 #pragma unroll
@@ -570,7 +617,7 @@ __global__ __launch_bounds__(256, 4) void igemm_dma_kernel(IgemmParams p, unsign
         }
     }
     __syncthreads();
-    igemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, mtile);
+    igemm_epilogue<T, BM, BN, PF>(p, acc, smem_raw, m0, n0, mtile, &er);
 }
 
 
@@ -702,6 +749,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
 int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
                             // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
+const bool g_epi_prefetch = [] { const char* e = getenv("CELLSEG_NO_EPI_PREFETCH"); return !(e && atoi(e)); }();   // A/B experiments only
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
 
 int igemm_mode(const IgemmParams& p) {
@@ -751,6 +799,14 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
         }
         CS_LAUNCH_CHECK();
         return CS_OK;
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (dma && mode != 2 && nk_host > 1 && (p.residual || p.mask) && p.dst_step == 1 && g_epi_prefetch) {
+            if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+            else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+            CS_LAUNCH_CHECK();
+            return CS_OK;
+        }
     }
     if (dma) {
         switch (mode) {
