@@ -233,7 +233,7 @@ def main():
     # same torch.optim.Adam the reference constructs (train_tile.py:282); fused=True is torch's single-launch
     # multi-tensor implementation of that update (the default foreach path is ~15 launches and 0.7 ms per step)
     opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4, fused=dev.type == "cuda")
-    reducer = GradReducer(params) if world > 1 else None
+    reducer = GradReducer(params).attach() if world > 1 else None       # buckets leave from inside the HIP backward
     if reducer is not None:
         reducer.broadcast_parameters(model)
 

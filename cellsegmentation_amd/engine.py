@@ -325,12 +325,36 @@ def compute_requires(plan, param_needs, input_needs):
     return requires, unit_trainable
 
 
+def _geom_key(geom):
+    return (geom.N, geom.H, geom.W, geom.C, geom.K, geom.R, geom.S, geom.stride, geom.pad)
+
+
+def _defers(u, a, need, ui):
+    """Eval-BN, ungrouped, bias-free convolutions whose weight AND BN gradients are wanted take the batched path."""
+    return (u.kind == "conv" and need(ui, "weight") and (need(ui, "gamma") or need(ui, "beta")) and not need(ui, "bias")
+            and not a.train and not u.grouped and u.bn is not None and u.conv.bias is None)
+
+
+_grad_sink = None
+
+
+def set_grad_sink(sink):
+    """Data-parallel hook (parallel.GradReducer.attach): `sink.view_for(param)` may hand out the tensor a parameter
+    gradient is to be written into (a slice of a flat all-reduce bucket) and `sink.deliver(param, grad)` is called, in
+    the order gradients are finished inside backward, as soon as the kernels producing `grad` are enqueued -- so the
+    bucket's collective can start while the rest of backward still runs.  Returns the previous sink."""
+    global _grad_sink
+    prev, _grad_sink = _grad_sink, sink
+    return prev
+
+
 def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
     """grad_feeds: {output slot: grad (already ReLU-masked where the slot is post-ReLU)}.
     Returns ({input slot: grad}, [param grads in plan.param_list order])."""
     t, aux = state.t, state.aux
     grads = dict(grad_feeds)
     gsum_cache = {}
+    sink = _grad_sink
     # One zero-filled fp32 arena for every raw weight-gradient buffer and column-sum vector of this backward pass
     # (a single fill kernel instead of ~2 per convolution).
     need_w_units, arena_elems = set(), 0
@@ -365,6 +389,54 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
     def need(ui, role):
         i = pindex.get((ui, role))
         return i is not None and param_needs[i]
+
+    def emit(ui, role, g):
+        """Record a finished parameter gradient (and hand it to the data-parallel sink straight away)."""
+        i = pindex[(ui, role)]
+        pgrads[i] = g if sink is None else sink.deliver(plan.param_list[i][2], g)
+
+    def grad_buffer(param, shape=None):
+        """Destination for a parameter gradient: the sink's bucket slice when there is one."""
+        v = sink.view_for(param) if sink is not None else None
+        if v is not None:
+            return v
+        return torch.empty_like(param) if shape is None else torch.empty(shape, dtype=torch.float32, device=param.device)
+
+    # how many layers of each geometry will ask for a batched weight gradient: a group is launched as soon as it is complete
+    # (or holds 8 layers), so its gradients are final -- and its activations released -- long before backward ends
+    group_total = {}
+    for ui_, u_ in enumerate(plan.units):
+        if ui_ in need_w_units and aux[ui_] is not None and _defers(u_, aux[ui_], need, ui_):
+            k_ = _geom_key(aux[ui_].geom)
+            group_total[k_] = group_total.get(k_, 0) + 1
+    group_seen = {}
+
+    def flush(items):
+        geom = items[0].a.geom
+        n = len(items)
+        convs = [it.u.conv for it in items]
+        Cin = convs[0].in_channels
+        dws = [grad_buffer(c.weight) for c in convs]
+        dgs = [grad_buffer(it.u.bn.weight) for it in items]
+        dbs = [grad_buffer(it.u.bn.bias) for it in items]
+        dots = [take((convs[0].out_channels,)) for _ in items]
+        if n == 1:
+            it = items[0]
+            raw = K.new_wgrad_buffer(geom, it.x.device)
+            K.conv_wgrad(geom, it.x, it.dz, raw, use_tr_read=use_tr_read)
+            K.wgrad_finalize(raw, convs[0].weight.detach(), it.a.st.scale, it.a.st.rstd, it.u.bn.running_mean, it.gsum, Cin, dws[0],
+                             dgamma=dgs[0], dbeta=dbs[0], dot=dots[0])
+        else:
+            slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
+            K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
+                                     [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
+                                     dws, dgs, dbs, dots, Cin)
+        for it, dw, dg, db in zip(items, dws, dgs, dbs):
+            emit(it.ui, "weight", dw)
+            if need(it.ui, "gamma"):
+                emit(it.ui, "gamma", dg)
+            if need(it.ui, "beta"):
+                emit(it.ui, "beta", db)
 
     def contribute(slot, g, masked):
         """Non-fused contribution (alias when first)."""
@@ -401,20 +473,23 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 dz, dgamma, dbeta = K.bn_bwd(g, a.z, a.mean, a.rstd, bn.weight.detach(), want_param_grads=want_bn,
                                              beta=bn.bias.detach(), act=ACT_SILU if u.act == ACT_SILU else ACT_NONE)
                 if need(ui, "gamma"):
-                    pgrads[pindex[(ui, "gamma")]] = dgamma[:Kc]
+                    emit(ui, "gamma", dgamma[:Kc])
                 if need(ui, "beta"):
-                    pgrads[pindex[(ui, "beta")]] = dbeta[:Kc]
-            defer = (want_w and want_bn and not want_b and not a.train and not u.grouped and u.bn is not None and conv.bias is None)
-            if defer:
-                # weight gradients of identical-geometry layers are launched together after the loop (one batched split-K
-                # launch per shape group: proportionally fewer partial slabs to write and fold)
+                    emit(ui, "beta", dbeta[:Kc])
+            if _defers(u, a, need, ui):
+                # weight gradients of identical-geometry layers are launched together (one batched split-K launch per shape
+                # group: proportionally fewer partial slabs to write and fold)
                 gsum = gsum_cache.pop(u.dst, None)
                 if gsum is None:
                     gsum = K.colsum(dz)
                 if u.res is not None and grads.get(u.res) is g:
                     gsum_cache[u.res] = gsum
-                key = (geom.N, geom.H, geom.W, geom.C, geom.K, geom.R, geom.S, geom.stride, geom.pad)
-                deferred.setdefault(key, []).append(SimpleNamespace(ui=ui, u=u, a=a, x=x, dz=dz, gsum=gsum))
+                key = _geom_key(geom)
+                items = deferred.setdefault(key, [])
+                items.append(SimpleNamespace(ui=ui, u=u, a=a, x=x, dz=dz, gsum=gsum))
+                group_seen[key] = group_seen.get(key, 0) + 1
+                if len(items) == 8 or group_seen[key] == group_total.get(key, 0):      # kernel-argument tables hold at most 8 layers
+                    flush(deferred.pop(key))
             elif want_w or want_b or (want_bn and not a.train):
                 gsum = None
                 if want_b or (want_bn and not a.train):
@@ -425,12 +500,11 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
                 raw = K.new_wgrad_buffer(geom, x.device, u.grouped)
                 K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
-                dw = torch.empty_like(conv.weight)
-                dbias = torch.empty_like(conv.bias) if want_b else None
+                dw = grad_buffer(conv.weight)
+                dbias = grad_buffer(conv.bias) if want_b else None
                 dgamma = dbeta = None
                 if want_bn and not a.train:
-                    dgb = torch.empty((2, Kc), dtype=torch.float32, device=x.device)
-                    dgamma, dbeta = dgb[0], dgb[1]
+                    dgamma, dbeta = grad_buffer(u.bn.weight), grad_buffer(u.bn.bias)
                 dot = take((Kc,)) if dgamma is not None else None
                 if u.grouped:
                     K.wgrad_finalize_grouped(raw, conv.weight.detach() if dgamma is not None else None, None if a.train else a.st.scale,
@@ -441,14 +515,14 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                                      None if a.train else a.st.rstd, u.bn.running_mean if dgamma is not None else None, gsum, Cin, dw,
                                      dbias=dbias, dgamma=dgamma, dbeta=dbeta, dot=dot)
                 if want_w:
-                    pgrads[pindex[(ui, "weight")]] = dw
+                    emit(ui, "weight", dw)
                 if want_b:
-                    pgrads[pindex[(ui, "bias")]] = dbias
+                    emit(ui, "bias", dbias)
                 if dgamma is not None:
                     if need(ui, "gamma"):
-                        pgrads[pindex[(ui, "gamma")]] = dgamma
+                        emit(ui, "gamma", dgamma)
                     if need(ui, "beta"):
-                        pgrads[pindex[(ui, "beta")]] = dbeta
+                        emit(ui, "beta", dbeta)
             gsum_cache.pop(u.dst, None)
             if requires.get(u.src, False):
                 left[u.src] -= 1
@@ -468,11 +542,11 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             dz, dgamma, dbeta = K.bn_bwd(g, a.z, a.mean, a.rstd, bn.weight.detach(), want_param_grads=want_bn, beta=bn.bias.detach(),
                                          act=ACT_SILU if u.act == ACT_SILU else ACT_NONE)
             if need(ui, "gamma"):
-                pgrads[pindex[(ui, "gamma")]] = dgamma
+                emit(ui, "gamma", dgamma)
             if need(ui, "beta"):
-                pgrads[pindex[(ui, "beta")]] = dbeta
+                emit(ui, "beta", dbeta)
             if need(ui, "weight"):
-                pgrads[pindex[(ui, "weight")]] = K.dwconv_wgrad(a.geom, x, dz).permute(2, 0, 1).unsqueeze(1).contiguous()
+                emit(ui, "weight", K.dwconv_wgrad(a.geom, x, dz).permute(2, 0, 1).unsqueeze(1).contiguous())
             if requires.get(u.src, False):
                 left[u.src] -= 1
                 dx = K.dwconv_dgrad(a.geom, dz, a.w_hwc)
@@ -486,13 +560,13 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             dh1, dw2, db2 = K.linear_bwd(a.h1, a.w2, ds, a.s, K.CS_ACT_SIGMOID, True, want2, want2)
             davg, dw1, db1 = K.linear_bwd(a.avg, a.w1, dh1, a.u1, K.CS_ACT_SILU, True, want1, want1)
             if need(ui, "w2"):
-                pgrads[pindex[(ui, "w2")]] = dw2.view_as(u.fc2.weight)
+                emit(ui, "w2", dw2.view_as(u.fc2.weight))
             if need(ui, "b2"):
-                pgrads[pindex[(ui, "b2")]] = db2
+                emit(ui, "b2", db2)
             if need(ui, "w1"):
-                pgrads[pindex[(ui, "w1")]] = dw1.view_as(u.fc1.weight)
+                emit(ui, "w1", dw1.view_as(u.fc1.weight))
             if need(ui, "b1"):
-                pgrads[pindex[(ui, "b1")]] = db1
+                emit(ui, "b1", db1)
             if requires.get(u.src, False):
                 left[u.src] -= 1
                 if u.src in grads:
@@ -525,34 +599,8 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                     contribute(u.a, ga, masked=True)
                 if nb:
                     contribute(u.b, gb, masked=True)
-    chunks = []
-    for items in deferred.values():
-        chunks += [items[i:i + 8] for i in range(0, len(items), 8)]       # kernel-argument tables hold at most 8 layers
-    for items in chunks:
-        geom = items[0].a.geom
-        n = len(items)
-        convs = [it.u.conv for it in items]
-        Kc, Cin = convs[0].out_channels, convs[0].in_channels
-        dws = [torch.empty_like(c.weight) for c in convs]
-        dgb = [torch.empty((2, Kc), dtype=torch.float32, device=dws[0].device) for _ in items]
-        dots = [take((Kc,)) for _ in items]
-        if n == 1:
-            it = items[0]
-            raw = K.new_wgrad_buffer(geom, it.x.device)
-            K.conv_wgrad(geom, it.x, it.dz, raw, use_tr_read=use_tr_read)
-            K.wgrad_finalize(raw, convs[0].weight.detach(), it.a.st.scale, it.a.st.rstd, it.u.bn.running_mean, it.gsum, Cin, dws[0],
-                             dgamma=dgb[0][0], dbeta=dgb[0][1], dot=dots[0])
-        else:
-            slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
-            K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
-                                     [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
-                                     dws, [d[0] for d in dgb], [d[1] for d in dgb], dots, Cin)
-        for it, dw, d in zip(items, dws, dgb):
-            pgrads[pindex[(it.ui, "weight")]] = dw
-            if need(it.ui, "gamma"):
-                pgrads[pindex[(it.ui, "gamma")]] = d[0]
-            if need(it.ui, "beta"):
-                pgrads[pindex[(it.ui, "beta")]] = d[1]
+    for items in list(deferred.values()):       # groups whose count fell short of the forecast (defensive; not expected)
+        flush(items)
     return {s: grads.get(s) for s in plan.inputs}, pgrads
 
 

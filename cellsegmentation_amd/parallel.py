@@ -1,39 +1,90 @@
 """Data-parallel gradient exchange: one process per GPU, RCCL (`backend="nccl"`) over xGMI.
 
 The tile minibatch shards by bag across ranks: forward/backward are rank-local (no SyncBN
-in the reference), and the only collective is one SUM all-reduce of the trainable gradients per
-step, divided by world size -- what the reference's DistributedDataParallel stub
-(train_tile.py:228-235) would do implicitly.  Gradients are packed into a few large flat fp32
-buckets (fewer, larger collectives suit point-to-point xGMI links), reduced on a dedicated stream so
-packing bucket k+1 overlaps the collective of bucket k, then scaled and unpacked.
-Works unchanged with the ``gloo`` backend on CPU tensors (unit tests).
+in the reference), and the only collective is a SUM all-reduce of the trainable gradients per step,
+divided by world size -- what the reference's DistributedDataParallel stub (train_tile.py:228-235)
+would do implicitly.
+
+Gradients live in a few flat fp32 buckets (fewer, larger collectives suit point-to-point xGMI links):
+
+* ``attach()`` registers the reducer as the engine's gradient sink.  The HIP backward then writes each
+  weight / BN gradient straight into its bucket slice (no pack copy) and reports it the moment its kernels
+  are enqueued; a bucket whose last gradient has arrived is all-reduced on a side stream while the rest of
+  backward keeps the compute queue busy.  Buckets are laid out in the order gradients were seen to finish
+  during the first step (deepest layers first), so the big layer3/layer4 buckets -- ~90 % of the bytes of a
+  ResNet-50 -- are on the wire long before the stem's gradients exist.
+* ``reduce()`` (after ``backward()``, before ``optimizer.step()``) sends whatever has not gone yet
+  (gradients produced outside the engine, e.g. the classifier head), waits for the side stream and makes
+  every ``p.grad`` hold the average.
+
+One ``backward()`` per ``reduce()`` (the reference's loops: zero_grad -> backward -> step), with
+``zero_grad(set_to_none=True)`` (torch's default) so autograd adopts the bucket slices as ``.grad``
+instead of accumulating into a stale tensor; anything else falls back to the post-backward path for that
+step.  Works unchanged with the ``gloo`` backend (CPU tensors in the unit tests, CUDA tensors in the
+one-GPU two-process rehearsal).
 """
 import torch
 import torch.distributed as dist
 
+from . import engine as _engine
+
+_ALIGN = 64      # floats: every bucket slice starts on a 256-byte boundary
+
+
+class _Bucket:
+    __slots__ = ("flat", "items", "pending", "launched")
+
+    def __init__(self, n, device):
+        self.flat = torch.zeros((n,), dtype=torch.float32, device=device)
+        self.items = []          # (param, offset, numel)
+        self.pending = 0
+        self.launched = False
+
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []          # [(flat buffer, [(param, offset, numel)])]
+        self.bucket_bytes = int(bucket_bytes)
+        self._stream = None
+        self._attached = False
+        self._order = []           # parameters in the order the engine finished them (recorded on the first attached step)
+        self._order_ids = set()
+        self._overlap_ok = True    # this step: gradients may be reduced from inside backward
+        self._slot = {}            # id(param) -> (bucket, offset, numel)
+        self.launches_in_backward = 0     # buckets sent before reduce() in the last step (diagnostics / tests)
+        self._build(list(reversed(self.params)))       # reverse order ~ the order gradients become ready
+
+    # ------------------------------------------------------------------ layout
+    def _build(self, ordered):
+        self.buckets, self._slot = [], {}
         cur, cur_n = [], 0
-        # reverse order = the order gradients become ready in backward
-        for p in reversed(self.params):
+
+        def close():
+            b = _Bucket(cur_n, cur[0][0].device)
+            for p, o, n in cur:
+                b.items.append((p, o, n))
+                self._slot[id(p)] = (b, o, n)
+            self.buckets.append(b)
+
+        for p in ordered:
             n = p.numel()
-            if cur and (cur_n + n) * 4 > bucket_bytes:
-                self._close(cur, cur_n)
+            if cur and (cur_n + n) * 4 > self.bucket_bytes:
+                close()
                 cur, cur_n = [], 0
             cur.append((p, cur_n, n))
-            cur_n += n
+            cur_n += (n + _ALIGN - 1) // _ALIGN * _ALIGN
         if cur:
-            self._close(cur, cur_n)
-        self._stream = None
+            close()
+        self._begin_step()
 
-    def _close(self, items, n):
-        dev = items[0][0].device
-        self.buckets.append((torch.zeros((n,), dtype=torch.float32, device=dev), items))
+    def _begin_step(self):
+        for b in self.buckets:
+            b.pending = len(b.items)
+            b.launched = False
+        self._overlap_ok = True
+        self._delivered = set()
 
     def broadcast_parameters(self, module, src=0):
         """DDP-constructor semantics: rank `src`'s parameters and buffers everywhere."""
@@ -42,37 +93,107 @@ class GradReducer:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src, group=self.group)
 
+    # ------------------------------------------------------------------ engine-facing (gradient sink)
+    def attach(self):
+        """Reduce from inside the HIP backward (see the module docstring).  Returns self."""
+        _engine.set_grad_sink(self)
+        self._attached = True
+        return self
+
+    def detach(self):
+        if self._attached:
+            _engine.set_grad_sink(None)
+            self._attached = False
+
+    def view_for(self, param):
+        """Bucket slice the engine should write this parameter's gradient into (None: not one of ours)."""
+        s = self._slot.get(id(param))
+        if s is None or self.world == 1 or param.grad is not None:      # an existing .grad may BE this slice: never write under it
+            return None
+        b, o, n = s
+        if b.launched:
+            raise RuntimeError("GradReducer: a second backward() before reduce(); call reduce() once per backward")
+        return b.flat[o:o + n].view_as(param)
+
+    def deliver(self, param, grad):
+        """The kernels producing `grad` are enqueued on the current stream.  Returns the tensor autograd should see."""
+        s = self._slot.get(id(param))
+        if s is None or self.world == 1:
+            return grad
+        if id(param) not in self._order_ids:
+            self._order_ids.add(id(param))
+            self._order.append(param)
+        b, o, n = s
+        if b.launched:
+            raise RuntimeError("GradReducer: a second backward() before reduce(); call reduce() once per backward")
+        if param.grad is not None:
+            # autograd will ACCUMULATE `grad` into .grad (which may alias our slice) after we return: leave the slice alone,
+            # send nothing of this bucket early; reduce() picks the total up from .grad
+            self._overlap_ok = False
+            return grad
+        view = b.flat[o:o + n].view_as(param)
+        if grad.data_ptr() != view.data_ptr():
+            view.copy_(grad)
+        self._delivered.add(id(param))
+        b.pending -= 1
+        if b.pending == 0 and self._overlap_ok and self._layout_final:
+            self._launch(b)
+        return view
+
+    # ------------------------------------------------------------------ collectives
+    def _launch(self, b):
+        inv = 1.0 / self.world
+        if b.flat.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+                b.flat.mul_(inv)
+        else:
+            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+            b.flat.mul_(inv)
+        b.launched = True
+
+    _layout_final = False
+
     @torch.no_grad()
     def reduce(self):
-        """All-reduce(SUM)/world of every .grad, in place."""
+        """All-reduce(SUM)/world of every .grad, in place (finishes what backward has not already sent)."""
         if self.world == 1:
             return
-        cuda = self.buckets and self.buckets[0][0].is_cuda
-        if cuda and self._stream is None:
-            self._stream = torch.cuda.Stream()
-        works = []
-        for flat, items in self.buckets:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p, _, _ in items]
-            views = [flat[o:o + n].view_as(g) for (_, o, n), g in zip(items, grads)]
-            torch._foreach_copy_(views, grads)
-            if cuda:
-                self._stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._stream):
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            else:
-                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
-        if cuda:
-            torch.cuda.current_stream().wait_stream(self._stream)
-        inv = 1.0 / self.world
-        for flat, items in self.buckets:
-            flat.mul_(inv)
-            for p, o, n in items:
+        sent_early = sum(1 for b in self.buckets if b.launched)
+        for b in self.buckets:
+            if b.launched:
+                continue
+            # pack what the engine did not write in place: gradients that came through plain autograd, or every gradient when
+            # this step could not overlap (accumulation into an existing .grad)
+            for p, o, n in b.items:
+                view = b.flat[o:o + n].view_as(p)
                 if p.grad is None:
-                    p.grad = flat[o:o + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[o:o + n].view_as(p))
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+            self._launch(b)
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        for b in self.buckets:
+            for p, o, n in b.items:
+                view = b.flat[o:o + n].view_as(p)
+                if p.grad is None:
+                    p.grad = view.clone()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    p.grad.copy_(view)
+        if self._attached and not self._layout_final and self._order:
+            # first attached step done: lay the buckets out in the order the engine finishes gradients (everything the engine
+            # never reported goes last, it is only available after backward anyway).  Old slices that .grad may still alias
+            # stay alive through those tensors; the next zero_grad() drops them.
+            rest = [p for p in reversed(self.params) if id(p) not in self._order_ids]
+            self._layout_final = True
+            self._build(self._order + rest)
+        else:
+            self._begin_step()
+        self.launches_in_backward = sent_early
 
 
 def shard_bags(n_bags, rank, world):

@@ -57,6 +57,91 @@ def test_grad_reducer_world2_gloo():
     assert all(nb > 1 for _, _, nb in res)
 
 
+def _emulated_backward(red, params, rank, step):
+    """What engine.backward + autograd's AccumulateGrad do with a gradient sink: ask for the destination, write the
+    rank-local gradient there, report it, then adopt (or accumulate) the returned tensor as .grad.  Deepest first."""
+    for i, p in reversed(list(enumerate(params))):
+        g = torch.full_like(p, float((rank + 1) * (i + 1) + step))
+        v = red.view_for(p)
+        if v is not None:
+            v.copy_(g)
+            g = v
+        out = red.deliver(p, g)
+        if p.grad is None:
+            p.grad = out
+        else:
+            p.grad += out
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 300, 5, 129, 64, 2)]
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    red = GradReducer(params + [frozen], bucket_bytes=1024).attach()
+    early, ok = [], True
+
+    def mean_local(i, step):
+        return sum(float((r + 1) * (i + 1) + step) for r in range(world)) / world
+
+    for step in range(3):                                  # zero_grad(set_to_none=True) loops
+        for p in params:
+            p.grad = None
+        _emulated_backward(red, params, rank, step)
+        red.reduce()
+        early.append(red.launches_in_backward)
+        for i, p in enumerate(params):
+            ok = ok and torch.allclose(p.grad, torch.full_like(p, mean_local(i, step)))
+    # no zero_grad at all: gradients accumulate into the (bucket-aliasing) .grad, nothing may be sent early
+    before = [p.grad.clone() for p in params]
+    _emulated_backward(red, params, rank, 7)
+    red.reduce()
+    acc_early = red.launches_in_backward
+    for i, p in enumerate(params):
+        ok = ok and torch.allclose(p.grad, before[i] + mean_local(i, 7))
+    # and the normal loop still works afterwards
+    for p in params:
+        p.grad = None
+    _emulated_backward(red, params, rank, 9)
+    red.reduce()
+    for i, p in enumerate(params):
+        ok = ok and torch.allclose(p.grad, torch.full_like(p, mean_local(i, 9)))
+    # a second backward without reduce() is refused instead of silently double-counting
+    for p in params:
+        p.grad = None
+    _emulated_backward(red, params, rank, 1)
+    refused = False
+    try:
+        for p in params:
+            p.grad = None
+        _emulated_backward(red, params, rank, 1)
+    except RuntimeError:
+        refused = True
+    red.detach()
+    q.put((rank, bool(ok), early, acc_early, refused, len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_overlaps_from_inside_backward_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ok, early, acc_early, refused, nb in res:
+        assert ok
+        assert nb > 1
+        assert early[0] == 0                 # first step only records the order gradients finish in
+        assert early[1] == nb and early[2] == nb      # afterwards every bucket leaves during backward
+        assert acc_early == 0
+        assert refused
+
+
 def test_shard_bags_never_splits_a_bag():
     shards = [shard_bags(10, r, 4) for r in range(4)]
     assert sorted(sum(shards, [])) == list(range(10))
