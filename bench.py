@@ -76,7 +76,7 @@ def kernel_name(kind, g, dtype):
     """Name of the kernel instantiation the C dispatcher picks for this launch (mirrors conv_igemm.hip)."""
     dt = "bf16" if dtype == torch.bfloat16 else "f32"
     if kind == "wgrad":
-        return f"wgrad_kernel<{dt},{128 if g['K'] > 64 else 64},128>"
+        return f"wgrad_kernel<{dt},{128 if g['K'] > 64 else 64},128,{'true' if dt == 'bf16' else 'false'}>"     # TR: transposing LDS reads (bf16)
     if kind == "fwd":
         M, nout, suffix = g["N"] * g["P"] * g["Q"], g["K"], ""
     else:
@@ -86,7 +86,10 @@ def kernel_name(kind, g, dtype):
             suffix = f" x{g['stride'] ** 2} parity classes"
     bm, bn = K.igemm_tile(M, nout)
     mode = 0 if (g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0) else 1
-    return f"igemm_dma_kernel<{dt},{bm},{bn},{mode}>{suffix}"
+    # epilogue-operand prefetch variant: bf16, more than one 64-element K-step, a residual/add/mask operand, identity destination
+    contracted = (g["C"] if kind == "fwd" else g["K"]) * g["R"] * g["S"]
+    pf = dt == "bf16" and contracted > 64 and g["extra"] > 0 and not suffix
+    return f"igemm_dma_kernel<{dt},{bm},{bn},{mode},{'true' if pf else 'false'}>{suffix}"
 
 
 def roofline_from(records, steps, dtype):

@@ -1022,6 +1022,7 @@ struct WgradParams {
     float* dw_tab[8];
     int n_items;
     int nsplit;
+    int nkt, tiles, total_z, per_xcd;   // output-channel tiles, output tiles per slice, slices x layers, work items per XCD
 };
 
 template <typename T, int BM, int BN, bool TR>
@@ -1049,10 +1050,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    const int k0 = blockIdx.x * BM;          // output-channel tile origin
-    const int q0 = blockIdx.y * BN;          // K-space (tap,c) element origin
-    const int item = p.n_items ? (int)(blockIdx.z / p.nsplit) : 0;
-    const int slice = p.n_items ? (int)(blockIdx.z % p.nsplit) : (int)blockIdx.z;
+    // XCD-aware order (1-D grid, workgroup id = 8*slot + xcd): all output tiles of one (layer, pixel slice) run back-to-back on
+    // ONE XCD, so the slice's dy / x rows -- which every one of those tiles reads -- come out of that XCD's L2 instead of being
+    // fetched once per XCD (measured 2.2-2.8x the algorithmic HBM bytes with the z-slowest 3-D grid).
+    // The (slice-major) list of slice x tile work items is cut into 8 contiguous runs, one per XCD.
+    const unsigned work = (blockIdx.x & 7) * (unsigned)p.per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= (unsigned)p.per_xcd || work >= (unsigned)p.total_z * (unsigned)p.tiles) return;
+    const int z = (int)(work / (unsigned)p.tiles);
+    const int tile = (int)(work % (unsigned)p.tiles);
+    const int k0 = (tile % p.nkt) * BM;      // output-channel tile origin
+    const int q0 = (tile / p.nkt) * BN;      // K-space (tap,c) element origin
+    const int item = p.n_items ? z / p.nsplit : 0;
+    const int slice = p.n_items ? z % p.nsplit : z;
     const long long mbeg = (long long)slice * p.m_per_split;
     long long mend = mbeg + p.m_per_split;
     if (mend > p.M) mend = p.M;
@@ -1273,7 +1282,11 @@ int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
     p.m_per_split = per;
     p.slab_stride = (long long)p.KO * p.QE;
     constexpr size_t lds = 2ull * BKP * (BM + BN + 2 * PADE) * sizeof(T);
-    dim3 grid(cs_ceil_div(p.KO, BM), cs_ceil_div(p.QE, BN), (unsigned)(nsplit * (n_items > 1 ? n_items : 1)));
+    p.nkt = cs_ceil_div(p.KO, BM);
+    p.tiles = p.nkt * cs_ceil_div(p.QE, BN);
+    p.total_z = nsplit * (n_items > 1 ? n_items : 1);
+    p.per_xcd = (p.total_z * p.tiles + 7) / 8;
+    dim3 grid((unsigned)(p.per_xcd * 8), 1, 1);
     hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
