@@ -74,6 +74,32 @@ template <> struct Mma<float> {
     }
 };
 
+// ---- hand-issued LDS-DMA -------------------------------------------------------------------------------------
+// `buffer_load_dwordx4 ... offen lds` written as inline asm ON PURPOSE.  Through the builtin, hipcc (ROCm 7.2) treats every
+// DMA as a pending LDS store that may alias any later LDS read and puts `s_waitcnt vmcnt(0)` in front of the first ds_read
+// of each K-step (and of every __syncthreads()): the stage requested a moment earlier is drained before the current one is
+// multiplied, i.e. NO copy/compute overlap inside a workgroup (seen in the .s of both DMA kernels; MFMA busy 23 %).  As asm
+// the DMA is invisible to that pass; ordering is ours: counted `s_waitcnt vmcnt(N)` + `dma_barrier()` before a stage is read.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);      // stride 0: raw buffer, offsets are bytes
+    r.z = (int)bytes;                                 // range check: offsets >= bytes read as zero
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+// 64 lanes x 16 bytes -> 1 KiB of LDS at `lds_base` (wave-uniform) + 16*lane; `voff` = per-lane byte offset into the buffer
+__device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned lds_base, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+// workgroup barrier that neither drains the VM queue nor lets the compiler move LDS accesses across it
+__device__ __forceinline__ void dma_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 // Epilogue operands (residual / add, mask) of one thread, fetched BEFORE the K loop so their latency hides behind it
 // (bf16 only: one 16-byte chunk = the thread's 8 channels).  Same row / channel-group ownership as igemm_epilogue.
 template <int BM, int BN> struct EpiRegs {
@@ -471,8 +497,9 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
     const int n0 = (int)(slot % n_ntiles) * BN;
     if (m0 >= p.M) return;     // grid is padded to 8 M tiles per round
 
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, wgt_bytes, 0x00020000);
+    const i32x4 rsrc_a = dma_rsrc(p.src, src_bytes);
+    const i32x4 rsrc_b = dma_rsrc(p.wgt, wgt_bytes);
+    const unsigned smem_base = lds_addr(smem_raw);
 
     const int lr = tid >> 3;                       // tile row of DMA instruction 0 (+32 per instruction)
     const int lc = (tid & 7) ^ ((lr >> 1) & 7);    // LOGICAL chunk column this lane fetches into physical slot tid&7
@@ -529,8 +556,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
     }
 
     auto issue = [&](int buf) {
-        unsigned char* As = smem_raw + (size_t)buf * STAGE * 16;
-        unsigned char* Bs = As + BM * 128;
+        const unsigned As = smem_base + (unsigned)buf * (STAGE * 16);
+        const unsigned Bs = As + BM * 128;
         const bool qok = q < p.Qtot;
         unsigned va[AI];
         if constexpr (MODE == 0) {
@@ -558,15 +585,13 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
         }
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (8 * wave + 32 * i) * 128), 16,
-                                                     (int)va[i], 0, 0, 0);
+            dma16(rsrc_a, As + (8 * wave + 32 * i) * 128, va[i]);
         int wqv = q;
         if constexpr (MODE != 0) wqv = ((p.wk0y + p.wkstep * kh) * p.S_full + p.wk0x + p.wkstep * kw) * p.SCc + cc;
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
             const unsigned vb = (qok && bbase[j] != OOB) ? bbase[j] + (unsigned)wqv * 16u : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (8 * wave + 32 * j) * 128), 16,
-                                                     (int)vb, 0, 0, 0);
+            dma16(rsrc_b, Bs + (8 * wave + 32 * j) * 128, vb);
         }
         // advance this lane's K position by one K-step (8 chunks)
         q += 8;
@@ -598,7 +623,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
     for (int ks = 0; ks < nk; ++ks) {
         if (ks == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile ks have landed
-        __syncthreads();                                    // ... and everybody else's; also frees the other buffer
+        dma_barrier();                                      // ... and everybody else's; also frees the other buffer
         if (ks >= 1 && ks + 1 < nk) issue((ks + 1) & 1);
         const uint4* As = smem + (ks & 1) * STAGE;
         const uint4* Bs = As + BM * 8;
@@ -1258,6 +1283,218 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA weight gradient (bf16, default): the [pixel][channel] tiles of dy and of the im2col view of x go global -> LDS with
+// `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass: the register-staged kernel above spends ~200 LDS-store
+// cycles per 256 MFMA cycles), through a ring of NST stages of 32 pixels with NST-1 stages in flight (counted vmcnt).
+//  * one wave-instruction fills 1 KiB of LDS = 4 rows of 256 B (8 rows of 128 B for the 64-channel dy tile); rows cannot be
+//    padded, so the conflict-free image for the transposing reads comes from an XOR on the 64-byte chunk group
+//    (256-B rows: group ^= row & 3; 128-B rows: group ^= (row >> 1) & 1), applied to the per-lane SOURCE chunk;
+//  * the lane's logical chunk -- hence its tap and channel -- is the same for every instruction and K-step (row & 3 and
+//    (row >> 1) & 1 are lane constants), only the pixel walks;
+//  * padding taps, pixel tails and channel / K-space tails are lanes with an out-of-range buffer offset (zeros).
+// Needs both operands < 2 GiB; grouped (slab) and fp32 weight gradients stay on the register-staged kernel.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int NST, bool PLAIN>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int BN = 128, BKP = 32;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_ROW_B = BM * 2, B_ROW_B = BN * 2;          // bytes per pixel row
+    constexpr int A_STAGE = BKP * A_ROW_B, B_STAGE = BKP * B_ROW_B;
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int A_RPI = 1024 / A_ROW_B, B_RPI = 1024 / B_ROW_B;     // rows per wave-instruction (4 or 8)
+    constexpr int A_I = BKP / A_RPI / 4, B_I = BKP / B_RPI / 4;       // instructions per wave per stage
+    static_assert(A_I >= 1 && B_I >= 1, "stage too small for 4 waves");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const unsigned work = (blockIdx.x & 7) * (unsigned)p.per_xcd + (blockIdx.x >> 3);      // see wgrad_kernel
+    if ((blockIdx.x >> 3) >= (unsigned)p.per_xcd || work >= (unsigned)p.total_z * (unsigned)p.tiles) return;
+    const int z = (int)(work / (unsigned)p.tiles);
+    const int tile = (int)(work % (unsigned)p.tiles);
+    const int k0 = (tile % p.nkt) * BM;
+    const int q0 = (tile / p.nkt) * BN;
+    const int item = p.n_items ? z / p.nsplit : 0;
+    const int slice = p.n_items ? z % p.nsplit : z;
+    const long long mbeg = (long long)slice * p.m_per_split;
+    long long mend = mbeg + p.m_per_split;
+    if (mend > p.M) mend = p.M;
+
+    const void* xsel = p.x;
+    const void* gsel = p.dy;
+    float* dsel = p.dw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (p.n_items && item == i) { xsel = p.x_tab[i]; gsel = p.dy_tab[i]; dsel = p.dw_tab[i]; }
+    const i32x4 rsrc_x = dma_rsrc(xsel, x_bytes);
+    const i32x4 rsrc_g = dma_rsrc(gsel, dy_bytes);
+    const unsigned smem_base = lds_addr(smem_raw);
+
+    // ---- A (dy) lanes: row-in-instruction and logical channel chunk
+    constexpr int A_CPR = A_ROW_B / 16;                        // chunks per row (16 or 8)
+    const int a_rl = lane / A_CPR;                             // row inside one instruction
+    const int a_slot = lane % A_CPR;
+    const int a_swz = A_ROW_B == 256 ? ((a_rl & 3) << 2) : (((a_rl >> 1) & 1) << 2);
+    const int a_ch = k0 + (a_slot ^ a_swz) * 8;
+    const unsigned a_col = a_ch < p.KO ? (unsigned)a_ch * 2u : OOB;
+    const unsigned g_row_b = (unsigned)p.KO * 2u;
+    // ---- B (im2col of x) lanes
+    const int b_rl = lane >> 4;
+    const int b_slot = lane & 15;
+    const int bq = q0 + (b_slot ^ ((b_rl & 3) << 2)) * 8;
+    const bool b_ok = bq < p.QE;
+    int b_kh = 0, b_kw = 0, b_c = 0;
+    if (b_ok) {
+        const int tap = bq / p.Cq;
+        b_c = bq - tap * p.Cq;
+        b_kh = tap / p.S;
+        b_kw = tap - b_kh * p.S;
+    }
+    // Pixel walk.  The stage's first pixel (img0, oy0, ox0) is wave-uniform and advances in scalar registers; a lane's row is
+    // that pixel + a lane constant < 32, folded back into (img, oy, ox) with two multiply-high divisions (exact: the
+    // dividends stay below Q + 64 resp. P + 8) -- the per-row divergent carry loops of the register-staged kernel cost more
+    // issue cycles per K-step than its 8 MFMAs.  PLAIN (1x1, stride 1, no padding): source pixel == destination pixel.
+    const unsigned magicQ = 0xffffffffu / (unsigned)p.Q + 1u, magicP = 0xffffffffu / (unsigned)p.P + 1u;
+    unsigned img0, oy0, ox0;
+    {
+        const long long img = mbeg / ((long long)p.P * p.Q);
+        const int rem = (int)(mbeg - img * (long long)p.P * p.Q);
+        img0 = (unsigned)img;
+        oy0 = (unsigned)(rem / p.Q);
+        ox0 = (unsigned)(rem - (int)oy0 * p.Q);
+    }
+    unsigned mstep = (unsigned)mbeg;                          // M * KO * 2 < 2 GiB: 32-bit pixel arithmetic throughout
+    const unsigned mend32 = (unsigned)mend;
+    const unsigned x_row_b = (unsigned)p.C * 2u;
+    const unsigned b_col = (unsigned)b_c * 2u;
+    const int b_dy = b_kh - p.pad, b_dx = b_kw - p.pad;
+
+    auto issue = [&](int buf) {
+        const unsigned As = smem_base + (unsigned)buf * STAGE;
+        const unsigned Bs = As + A_STAGE;
+#pragma unroll
+        for (int i = 0; i < A_I; ++i) {
+            const int r = (wave * A_I + i) * A_RPI;            // first row of this instruction
+            const unsigned m = mstep + (unsigned)(r + a_rl);
+            const unsigned va = (m < mend32 && a_col != OOB) ? m * g_row_b + a_col : OOB;
+            dma16(rsrc_g, As + r * A_ROW_B, va);
+        }
+#pragma unroll
+        for (int i = 0; i < B_I; ++i) {
+            const int r = (wave * B_I + i) * B_RPI;
+            const unsigned m = mstep + (unsigned)(r + b_rl);
+            unsigned vb = OOB;
+            if constexpr (PLAIN) {
+                if (b_ok && m < mend32) vb = m * x_row_b + b_col;
+            } else {
+                const unsigned t = ox0 + (unsigned)(r + b_rl);
+                const unsigned w = __umulhi(t, magicQ);
+                const unsigned ox = t - w * (unsigned)p.Q;
+                const unsigned u = oy0 + w;
+                const unsigned w2 = __umulhi(u, magicP);
+                const unsigned oy = u - w2 * (unsigned)p.P;
+                const int iy = (int)oy * p.stride + b_dy;
+                const int ix = (int)ox * p.stride + b_dx;
+                if (b_ok && m < mend32 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    vb = (((img0 + w2) * (unsigned)p.H + (unsigned)iy) * (unsigned)p.W + (unsigned)ix) * x_row_b + b_col;
+            }
+            dma16(rsrc_x, Bs + r * B_ROW_B, vb);
+        }
+        mstep += BKP;
+        if constexpr (!PLAIN) {
+            ox0 += BKP;
+            const unsigned w = __umulhi(ox0, magicQ);
+            ox0 -= w * (unsigned)p.Q;
+            oy0 += w;
+            const unsigned w2 = __umulhi(oy0, magicP);
+            oy0 -= w2 * (unsigned)p.P;
+            img0 += w2;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing-read lane constants: per 16-lane group a 4(pixel) x 16(channel) block, lane i16 gets the 4 pixels of channel i16
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int qq = i16 >> 2, pp = i16 & 3;
+    // byte offset inside a row of this lane's 8-byte piece, swizzle included (row & 3 == qq: kr below is a multiple of 4)
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ch = wm * (BM / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
+        const int sw = A_ROW_B == 256 ? (qq << 2) : (((qq >> 1) & 1) << 2);
+        a_off[i] = (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = wn * (BN / 2) + j * 32 + 16 * (g16 & 1) + 4 * pp;
+        b_off[j] = (((ch >> 3) ^ (qq << 2)) << 4) + (ch & 7) * 2;
+    }
+
+    constexpr int D = NST - 1;                                 // stages in flight
+    constexpr int PER = A_I + B_I;                             // DMA instructions per wave per stage
+    const int nk = (int)((mend - mbeg + BKP - 1) / BKP);
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0)
+        if (s0 < nk) issue(s0);
+    for (int ks = 0; ks < nk; ++ks) {
+        // stage ks has landed once at most min(D-1, nk-1-ks) younger stages are outstanding (vmcnt retires in issue order)
+        const int younger = (nk - 1 - ks) < (D - 1) ? (nk - 1 - ks) : (D - 1);
+        if (younger >= 2 && D >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (younger == 1 && D >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma_barrier();                                         // everybody's pieces landed; everybody is done with stage ks-1
+        if (ks + D < nk) issue((ks + D) % NST);
+        const unsigned char* As = smem_raw + (size_t)(ks % NST) * STAGE;
+        const unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int s = 0; s < BKP / 16; ++s) {
+            union Frag { bf16x8 v; s16x4 q[2]; };
+            Frag a[TM], b[TN];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kr = 16 * s + 8 * hh + 4 * u + qq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(As + kr * A_ROW_B + a_off[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + kr * B_ROW_B + b_off[j]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* slab = dsel + (long long)slice * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int qe = q0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = k0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ko < p.KO && qe < p.QE) slab[(long long)ko * p.QE + qe] = acc[i][j][r];
+            }
+        }
+}
+
 // number of split-K slices for KO x QE outputs over M pixels with a BM x 128 tile: ~512 workgroups (2 per CU);
 // every slice costs one extra write + read of the whole dW in fp32, so no more than needed to fill the chip
 int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
@@ -1270,6 +1507,9 @@ int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
     per = ((per + 31) / 32) * 32;
     return (int)((M + per - 1) / per);
 }
+
+const int g_wgrad_nst = [] { const char* e = getenv("CELLSEG_WGRAD_NST"); return e ? atoi(e) : 3; }();   // A/B experiments only
+const bool g_wgrad_dma = [] { const char* e = getenv("CELLSEG_WGRAD_REG"); return !(e && atoi(e)); }();   // A/B experiments only
 
 template <typename T, int BM, int BN, bool TR>
 int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
@@ -1287,6 +1527,25 @@ int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
     p.total_z = nsplit * (n_items > 1 ? n_items : 1);
     p.per_xcd = (p.total_z * p.tiles + 7) / 8;
     dim3 grid((unsigned)(p.per_xcd * 8), 1, 1);
+    if constexpr (sizeof(T) == 2 && TR && BN == 128) {
+        const unsigned long long x_bytes = (unsigned long long)(p.M / ((long long)p.P * p.Q)) * p.H * p.W * p.C * 2ull;
+        const unsigned long long g_bytes = (unsigned long long)p.M * p.KO * 2ull;
+        if (g_wgrad_dma && !p.slab && x_bytes < 0x80000000ull && g_bytes < 0x80000000ull) {
+            constexpr size_t stage = (size_t)32 * (BM + 128) * 2;
+            const bool plain = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+#define CS_WGRAD_DMA(NST_) \
+    do { \
+        if (plain) hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, true>), grid, dim3(256), NST_ * stage, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
+        else hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, false>), grid, dim3(256), NST_ * stage, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
+    } while (0)
+            if (g_wgrad_nst == 2) CS_WGRAD_DMA(2);
+            else if (g_wgrad_nst == 4) CS_WGRAD_DMA(4);
+            else CS_WGRAD_DMA(3);
+#undef CS_WGRAD_DMA
+            CS_LAUNCH_CHECK();
+            return CS_OK;
+        }
+    }
     hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
