@@ -855,12 +855,13 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 int igemm_tile(long long M, int NOUT) {
     static const int forced = [] { const char* e = getenv("CELLSEG_TILE"); return e ? atoi(e) : 0; }();   // experiments only
     if (forced) return (NOUT <= 64 && forced % 1000 == 128) ? forced - 64 : forced;
+    static const int thr = [] { const char* e = getenv("CELLSEG_TILE_THR"); return e ? atoi(e) : 384; }();   // experiments only
     const long long mt128 = (M + 127) / 128;
     if (NOUT > 64) {
         const long long blocks = mt128 * ((NOUT + 127) / 128);
-        return blocks >= 384 ? 128128 : 64128;
+        return blocks >= thr ? 128128 : 64128;
     }
-    return mt128 >= 384 ? 128064 : 64064;
+    return mt128 >= thr ? 128064 : 64064;
 }
 
 template <typename T>
@@ -1295,9 +1296,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 //  * padding taps, pixel tails and channel / K-space tails are lanes with an out-of-range buffer offset (zeros).
 // Needs both operands < 2 GiB; grouped (slab) and fp32 weight gradients stay on the register-staged kernel.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int NST, bool PLAIN>
+template <int BM, int NST, bool PLAIN, int BKP>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
-    constexpr int BN = 128, BKP = 32;
+    constexpr int BN = 128;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_ROW_B = BM * 2, B_ROW_B = BN * 2;          // bytes per pixel row
     constexpr int A_STAGE = BKP * A_ROW_B, B_STAGE = BKP * B_ROW_B;
@@ -1531,16 +1532,17 @@ int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
         const unsigned long long x_bytes = (unsigned long long)(p.M / ((long long)p.P * p.Q)) * p.H * p.W * p.C * 2ull;
         const unsigned long long g_bytes = (unsigned long long)p.M * p.KO * 2ull;
         if (g_wgrad_dma && !p.slab && x_bytes < 0x80000000ull && g_bytes < 0x80000000ull) {
-            constexpr size_t stage = (size_t)32 * (BM + 128) * 2;
             const bool plain = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
-#define CS_WGRAD_DMA(NST_) \
+#define CS_WGRAD_DMA(NST_, BKP_) \
     do { \
-        if (plain) hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, true>), grid, dim3(256), NST_ * stage, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
-        else hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, false>), grid, dim3(256), NST_ * stage, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
+        constexpr size_t stage_ = (size_t)BKP_ * (BM + 128) * 2; \
+        if (plain) hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, true, BKP_>), grid, dim3(256), NST_ * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
+        else hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, false, BKP_>), grid, dim3(256), NST_ * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
     } while (0)
-            if (g_wgrad_nst == 2) CS_WGRAD_DMA(2);
-            else if (g_wgrad_nst == 4) CS_WGRAD_DMA(4);
-            else CS_WGRAD_DMA(3);
+            if (g_wgrad_nst == 2) CS_WGRAD_DMA(2, 32);
+            else if (g_wgrad_nst == 4) CS_WGRAD_DMA(4, 32);
+            else if (g_wgrad_nst == 64) CS_WGRAD_DMA(2, 64);
+            else CS_WGRAD_DMA(3, 32);
 #undef CS_WGRAD_DMA
             CS_LAUNCH_CHECK();
             return CS_OK;
