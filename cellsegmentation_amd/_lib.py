@@ -18,6 +18,12 @@ class CsConvGeom(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "P", "Q")]
 
 
+class CsStageDesc(Structure):
+    """One layer of cs_stage_conv_bn_multi (include/cellseg_hip.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("w", "gamma", "beta", "mean", "var", "conv_bias", "w_khwc", "w_chwk", "scale", "shift", "rstd")]
+                + [("eps", c_float)] + [(n, c_int32) for n in ("K", "Cin", "R", "S", "Cp", "Kp", "block0")])
+
+
 class CellsegLibraryMissing(RuntimeError):
     pass
 
@@ -30,6 +36,8 @@ _SIGNATURES = {
     "cs_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_nhwc_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_bn_fold": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, _P]),
+    "cs_stage_conv_bn_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "cs_stage_conv_bn_multi": (c_int, [_P, c_int, c_int, c_int, _P]),
     "cs_stage_conv_bn": (c_int, [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "cs_weight_prep": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "cs_conv2d_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),

@@ -139,6 +139,57 @@ __global__ void stage_conv_bn_kernel(const float* __restrict__ w, const float* _
     }
 }
 
+// ---- every layer of a network in one launch: workgroup -> layer by binary search over the block0 prefix table
+constexpr int kStageElemsPerBlock = 2048;      // 256 threads x 8 staged elements
+
+template <typename T>
+__global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageDesc* __restrict__ desc, int n) {
+    __shared__ int which_s;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (desc[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        which_s = lo;
+    }
+    __syncthreads();
+    const int which = which_s;
+    const CsStageDesc d = desc[which];
+    const int nb = (which + 1 < n ? desc[which + 1].block0 : (int)gridDim.x) - d.block0;
+    const int b = (int)blockIdx.x - d.block0;
+    const int RS = d.R * d.S;
+    if (b == 0) {
+        for (int k = threadIdx.x; k < d.Kp; k += blockDim.x) {
+            float r = 0.f, sc = 0.f, sh = 0.f;
+            if (k < d.K) {
+                r = 1.0f / sqrtf(d.var[k] + d.eps);
+                sc = (d.gamma ? d.gamma[k] : 1.f) * r;
+                sh = (d.beta ? d.beta[k] : 0.f) + ((d.conv_bias ? d.conv_bias[k] : 0.f) - d.mean[k]) * sc;
+            }
+            d.scale[k] = sc; d.shift[k] = sh; d.rstd[k] = r;
+        }
+    }
+    T* w_khwc = reinterpret_cast<T*>(d.w_khwc);
+    T* w_chwk = reinterpret_cast<T*>(d.w_chwk);
+    const long long t1 = w_khwc ? (long long)d.Kp * RS * d.Cp : 0;
+    const long long t2 = w_chwk ? (long long)d.Cp * RS * d.Kp : 0;
+    for (long long idx = (long long)b * blockDim.x + threadIdx.x; idx < t1 + t2; idx += (long long)nb * blockDim.x) {
+        int k, c, rs;
+        const bool first = idx < t1;
+        if (first) {
+            c = (int)(idx % d.Cp); rs = (int)((idx / d.Cp) % RS); k = (int)(idx / ((long long)d.Cp * RS));
+        } else {
+            const long long j = idx - t1;
+            k = (int)(j % d.Kp); rs = (int)((j / d.Kp) % RS); c = (int)(j / ((long long)d.Kp * RS));
+        }
+        float v = 0.f;
+        if (k < d.K && c < d.Cin) v = d.w[((long long)k * d.Cin + c) * RS + rs] * ((d.gamma ? d.gamma[k] : 1.f) * (1.0f / sqrtf(d.var[k] + d.eps)));
+        if (first) w_khwc[idx] = from_f32<T>(v);
+        else w_chwk[idx - t1] = from_f32<T>(v);
+    }
+}
+
 // ---- grouped weights: fp32 [K][Cg][R][S] (x scale[k]) -> slab-dense T [K][R][S][64] and T [C][R][S][64]
 // (K == C, groups of Cg channels, 64-channel slabs; entries outside a channel's own group are zero)
 template <typename T>
@@ -474,6 +525,25 @@ extern "C" int cs_stage_conv_bn(const float* w, const float* gamma, const float*
                            conv_bias, K, Cin, R, S, Cp, Kp, (bf16_t*)w_khwc, (bf16_t*)w_chwk, scale, shift, rstd);
     else
         CS_CHECK_ARG(false, "stage_conv_bn: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_stage_conv_bn_blocks(int K, int Cin, int R, int S, int Cp, int Kp, int want_fwd, int want_bwd) {
+    if (K <= 0 || Cin <= 0 || R <= 0 || S <= 0 || Cp < Cin || Kp < K) return 0;
+    const long long total = (want_fwd ? (long long)Kp * R * S * Cp : 0) + (want_bwd ? (long long)Cp * R * S * Kp : 0);
+    long long b = (total + kStageElemsPerBlock - 1) / kStageElemsPerBlock;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+extern "C" int cs_stage_conv_bn_multi(const CsStageDesc* desc, int n, int total_blocks, int dtype, void* stream) {
+    CS_CHECK_ARG(desc && n >= 1 && total_blocks >= n, "stage_conv_bn_multi: need a device descriptor table and >= 1 workgroup per layer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CS_F32) hipLaunchKernelGGL(stage_conv_bn_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, st, desc, n);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(stage_conv_bn_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, desc, n);
+    else CS_CHECK_ARG(false, "stage_conv_bn_multi: bad dtype");
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

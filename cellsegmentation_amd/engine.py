@@ -225,6 +225,19 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
         if remaining[s] == 0:
             t.pop(s, None)
 
+    # Training passes re-stage every folded Conv+BN after each optimizer update: one launch for the whole plan (the first such
+    # pass stages layer by layer and records the layout; see kernels.StagePack)
+    packs = plan.__dict__.setdefault("_stage_packs", {})
+    pack = packs.get(dtype) if save else None
+    prestaged, record = {}, None
+    if save:
+        if pack is not None and pack.valid():
+            pack.launch()
+            prestaged = pack.by_unit
+        else:
+            packs.pop(dtype, None)
+            record = []
+
     for ui, u in enumerate(plan.units):
         if u.kind == "conv":
             x = t[u.src]
@@ -237,7 +250,16 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             res = t[u.res] if u.res is not None else None
             need_bwd = save and requires.get(u.src, False)
             batch_stats = _bn_uses_batch_stats(u.bn, bn_train)
-            st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save)
+            pre = prestaged.get(ui)
+            if pre is not None and pre[0] == (Cp, Kp, need_bwd) and not batch_stats:
+                st = pre[1]
+            else:
+                if pre is not None:
+                    packs.pop(dtype, None)          # the layout changed (other requires_grad pattern): rebuild next time
+                st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save)
+                if (record is not None and not batch_stats and u.bn is not None and not u.grouped
+                        and any(p_ is not None and p_.requires_grad for p_ in (conv.weight, conv.bias, u.bn.weight, u.bn.bias))):
+                    record.append((ui, conv, u.bn, Cp, Kp, need_bwd))
             if not batch_stats:
                 y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=False)
@@ -308,6 +330,12 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             aux[ui] = SimpleNamespace(ca=a.shape[-1])
         for s in u.inputs():
             release(s)
+    if record:
+        pk = K.StagePack([(conv_, bn_, cp_, kp_, nb_) for _, conv_, bn_, cp_, kp_, nb_ in record], dtype)
+        pk.by_unit = {}
+        for (ui_, _, _, cp_, kp_, nb_), (w_khwc, w_chwk, scale, shift, rstd) in zip(record, pk.staged):
+            pk.by_unit[ui_] = ((cp_, kp_, nb_), SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd))
+        packs[dtype] = pk
     return SimpleNamespace(t=t, aux=aux, in_hw=in_hw)
 
 

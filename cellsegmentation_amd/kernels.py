@@ -89,6 +89,55 @@ def stage_conv_bn(w, gamma, beta, mean, var, eps, conv_bias, dtype, Cp, Kp, want
     return w_khwc, w_chwk, vec[0], vec[1], vec[2]
 
 
+class StagePack:
+    """Every eval-mode Conv2d+BatchNorm2d of a network staged by ONE launch (cs_stage_conv_bn_multi).
+
+    layers: [(conv, bn, Cp, Kp, want_bwd)].  The staging buffers and the device descriptor table are allocated once and
+    rewritten by every launch(); valid() tells whether the parameter tensors are still the ones the table points at."""
+
+    def __init__(self, layers, dtype):
+        lib = _lib.load()
+        dev = layers[0][0].weight.device
+        self.dtype, self.layers, self.staged = dtype, layers, []
+        arr = (_lib.CsStageDesc * len(layers))()
+        block = 0
+        for i, (conv, bn, Cp, Kp, want_bwd) in enumerate(layers):
+            K_, Cin, R, S = conv.weight.shape
+            w_khwc = torch.empty((Kp, R, S, Cp), dtype=dtype, device=dev)
+            w_chwk = torch.empty((Cp, R, S, Kp), dtype=dtype, device=dev) if want_bwd else None
+            vec = torch.empty((3, Kp), dtype=torch.float32, device=dev)
+            d = arr[i]
+            d.w, d.gamma, d.beta = conv.weight.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
+            d.mean, d.var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            d.conv_bias = conv.bias.data_ptr() if conv.bias is not None else None
+            d.w_khwc, d.w_chwk = w_khwc.data_ptr(), (w_chwk.data_ptr() if want_bwd else None)
+            d.scale, d.shift, d.rstd = vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr()
+            d.eps = float(bn.eps)
+            d.K, d.Cin, d.R, d.S, d.Cp, d.Kp, d.block0 = K_, Cin, R, S, Cp, Kp, block
+            nb = lib.cs_stage_conv_bn_blocks(K_, Cin, R, S, Cp, Kp, 1, 1 if want_bwd else 0)
+            if nb < 1:
+                raise ValueError("StagePack: bad layer extents")
+            block += nb
+            self.staged.append((w_khwc, w_chwk, vec[0], vec[1], vec[2]))
+        self.total_blocks = block
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.key = self._key()
+
+    def _key(self):
+        out = []
+        for conv, bn, _, _, _ in self.layers:
+            for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var):
+                out.append(t.data_ptr() if t is not None else 0)
+        return tuple(out)
+
+    def valid(self):
+        return self._key() == self.key
+
+    def launch(self):
+        _lib.check(_lib.load().cs_stage_conv_bn_multi(self.table.data_ptr(), len(self.layers), self.total_blocks, _code(self.dtype), _stream()),
+                   "stage_conv_bn_multi")
+
+
 def weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=False):
     K, Cin, R, S = w.shape
     w_khwc = torch.empty((Kp, R, S, Cp), dtype=dtype, device=w.device) if want_fwd else None

@@ -92,6 +92,21 @@ int cs_stage_conv_bn(const float* w, const float* gamma, const float* beta, cons
                      const float* conv_bias, int dtype, int K, int Cin, int R, int S, int Cp, int Kp, void* w_khwc,
                      void* w_chwk, float* scale, float* shift, float* rstd, void* stream);
 
+/* The same for EVERY eval-mode Conv2d+BatchNorm2d of a network in ONE launch (a training step re-stages all ~53 layers of a
+ * ResNet-50 after each optimizer update: 53 launches of ~7 us otherwise).  `desc` is a DEVICE array of n descriptors, built once
+ * by the host for a fixed set of parameter / staging buffers; block0 = prefix sum of cs_stage_conv_bn_blocks() over the layers,
+ * total_blocks = the sum. */
+typedef struct CsStageDesc {
+    const float *w, *gamma, *beta, *mean, *var, *conv_bias;   /* gamma / beta / conv_bias nullable */
+    void *w_khwc, *w_chwk;                                     /* either nullable */
+    float *scale, *shift, *rstd;                               /* [Kp] */
+    float eps;
+    int32_t K, Cin, R, S, Cp, Kp;
+    int32_t block0;
+} CsStageDesc;
+int cs_stage_conv_bn_blocks(int K, int Cin, int R, int S, int Cp, int Kp, int want_fwd, int want_bwd);
+int cs_stage_conv_bn_multi(const CsStageDesc* desc, int n, int total_blocks, int dtype, void* stream);
+
 /* ---- convolution family (implicit GEMM on MFMA) ---------------------------------------------
  * forward: y = act( scale[k]*conv(x,w) + shift[k] + residual ), any of scale/shift/residual NULL.
  *   Fuses Conv2d+BatchNorm2d(eval)+ReLU(+residual add) of BasicBlock/Bottleneck.forward

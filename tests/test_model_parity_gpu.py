@@ -215,3 +215,51 @@ def test_bf16_throughput_mode_is_close(dev):
         logits = m(x)
     want = GOLD[f"{tag}/logits_eval"]
     assert rel(logits.float().cpu(), want) < 5e-2
+
+
+def test_one_launch_staging_equals_layer_by_layer(dev):
+    """The second and later training passes stage every folded Conv+BN with one launch (StagePack): logits and gradients
+    must equal those of the first (layer-by-layer) pass, also after the parameters changed in place."""
+    from cellsegmentation_amd import synth
+    from cellsegmentation_amd.model import resnet as R
+
+    def build():
+        m = R.MILresnet18()
+        sd = m.state_dict()
+        synth.fill_state_dict(sd)
+        m.load_state_dict(sd)
+        m = m.to(dev).set_compute_dtype(torch.float32)
+        m.setmode("tile")
+        m.set_encoder_grads(True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m.train()
+
+    x = synth.normalise(synth.ihc_tiles(8, 32, 91)).to(dev)
+    y = torch.tensor([0, 1, 0, 1, 1, 0, 1, 0], device=dev)
+
+    def step(m):
+        for p in m.parameters():
+            p.grad = None
+        out = m(x, freeze_bn=True)             # train_tile's call (train.py): BN folded, trunk trainable
+        torch.nn.functional.cross_entropy(out, y).backward()
+        return out.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    m = build()
+    o1, g1 = step(m)                       # layer by layer, records the pack
+    o2, g2 = step(m)                       # one launch
+    assert m._encoder_plan(False)._stage_packs, "the one-launch staging path was not taken"
+    # (BN-parameter gradients fold <W, dW> with float atomics: equal up to summation order, everything else bitwise)
+    close = lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-7)      # noqa: E731
+    assert torch.equal(o1, o2) and all(close(a, b) for a, b in zip(g1, g2))
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.requires_grad:
+                p.mul_(1.01)
+    o3, g3 = step(m)                       # one launch, new values
+    ref = build()
+    ref.load_state_dict(m.state_dict())
+    o4, g4 = step(ref)                     # layer by layer on a fresh model
+    assert float((o3 - o1).abs().max()) > 0
+    assert torch.equal(o3, o4) and all(close(a, b) for a, b in zip(g3, g4))

@@ -56,7 +56,7 @@ def _worker_body(rank, world, port, q):
     def local_grads(r):
         for p in params:
             p.grad = None
-        torch.nn.functional.cross_entropy(m(xs[r]), ys[r]).backward()
+        torch.nn.functional.cross_entropy(m(xs[r], freeze_bn=True), ys[r]).backward()
         return [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]      # tile mode leaves the image heads unused
 
     expect = [sum(gs) / world for gs in zip(*[local_grads(r) for r in range(world)])]      # no reducer involved
@@ -67,7 +67,7 @@ def _worker_body(rank, world, port, q):
     for step in range(3):
         for p in params:
             p.grad = None
-        torch.nn.functional.cross_entropy(m(xs[rank]), ys[rank]).backward()
+        torch.nn.functional.cross_entropy(m(xs[rank], freeze_bn=True), ys[rank]).backward()
         red.reduce()
         early.append(red.launches_in_backward)
         for p, e in zip(params, expect):
