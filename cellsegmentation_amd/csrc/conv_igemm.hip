@@ -875,7 +875,7 @@ int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream
         case 128064: rc = launch_igemm<T, 128, 64>(p, st); break;
         default: rc = launch_igemm<T, 64, 64>(p, st); break;
     }
-    if (rc != CS_OK || !p.slab) return rc;
+    if (rc != CS_OK || !p.slab || (!colsum && !stats)) return rc;      // no colsum/stats target: the partial rows are the result
     const int bm = tile / 1000;
     const int rows = (int)((p.M + bm - 1) / bm);
     const int ncols = stats ? 2 * p.NOUT : p.NOUT;
@@ -953,6 +953,68 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     return dtype == CS_F32 ? dispatch_igemm<float>(p, nullptr, stats, st) : dispatch_igemm<bf16_t>(p, nullptr, stats, st);
 }
 
+extern "C" int cs_conv2d_dgrad_partial_rows(const CsConvGeom* g) {
+    if (!g) return 0;
+    const long long M = (long long)g->N * g->H * g->W;
+    const int bm = igemm_tile(M, g->C) / 1000;
+    return (int)((M + bm - 1) / bm);
+}
+
+extern "C" int cs_fold_partial_rows(const float* partial, int rows, int n_out, float* out, void* stream) {
+    CS_CHECK_ARG(partial && out && rows > 0 && n_out > 0, "fold_partial_rows: bad arguments");
+    int chunks = rows / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 32) chunks = 32;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_out + 63) / 64, chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, rows,
+                       2 * n_out, n_out, n_out, out, (double*)nullptr);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+namespace {
+struct FoldTables { const float* partial[8]; float* out[8]; int rows[8]; };
+// slab_reduce_kernel over n <= 8 buffers: blockIdx.z = item (tables by value, static-index selection)
+__global__ __launch_bounds__(256) void fold_partial_batched_kernel(FoldTables t, int n_out) {
+    const float* src = nullptr; float* dst = nullptr; int rows = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((int)blockIdx.z == i) { src = t.partial[i]; dst = t.out[i]; rows = t.rows[i]; }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per;
+    int r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    float acc = 0.f;
+    if (c < n_out)
+        for (int r = r0 + rl; r < r1; r += 4) acc += src[(long long)r * 2 * n_out + c];
+    __shared__ float part[4][64];
+    part[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < n_out && r0 < rows)
+        atomicAdd(dst + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+}  // namespace
+
+extern "C" int cs_fold_partial_rows_batched(const float* const* partial_tab, const int* rows_tab, float* const* out_tab, int n_items,
+                                            int n_out, void* stream) {
+    CS_CHECK_ARG(partial_tab && rows_tab && out_tab && n_items >= 1 && n_items <= 8 && n_out > 0, "fold_partial_rows_batched: 1..8 items, HOST tables");
+    FoldTables t{};
+    int max_rows = 0;
+    for (int i = 0; i < n_items; ++i) {
+        CS_CHECK_ARG(partial_tab[i] && out_tab[i] && rows_tab[i] > 0, "fold_partial_rows_batched: NULL buffer or no rows");
+        t.partial[i] = partial_tab[i]; t.out[i] = out_tab[i]; t.rows[i] = rows_tab[i];
+        if (rows_tab[i] > max_rows) max_rows = rows_tab[i];
+    }
+    int chunks = max_rows / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 32) chunks = 32;
+    hipLaunchKernelGGL(fold_partial_batched_kernel, dim3((n_out + 63) / 64, chunks, n_items), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
+                       n_out);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
 extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                                const void* mask, void* dx, float* colsum, void* workspace, void* stream) {
     const int slab = g_next_slab;
@@ -968,7 +1030,9 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     IgemmParams p{};
     p.src = dy; p.wgt = w_chwk; p.dst = dx;
     p.scale = nullptr; p.shift = nullptr; p.residual = add; p.mask = mask;
-    p.slab = colsum ? reinterpret_cast<float*>(workspace) : nullptr;
+    const bool deferred = !colsum && workspace;
+    CS_CHECK_ARG(!deferred || (g->stride == 1 && !slab), "conv2d_dgrad: deferred column sums need a stride-1, ungrouped launch");
+    p.slab = (colsum || deferred) ? reinterpret_cast<float*>(workspace) : nullptr;
     p.SH = g->P; p.SW = g->Q; p.SC = g->K;
     p.DH = g->H; p.DW = g->W; p.NOUT = g->C;
     p.R = g->R; p.S = g->S;

@@ -448,17 +448,13 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         dgs = [grad_buffer(it.u.bn.weight) for it in items]
         dbs = [grad_buffer(it.u.bn.bias) for it in items]
         dots = [take((convs[0].out_channels,)) for _ in items]
-        if n == 1:
-            it = items[0]
-            raw = K.new_wgrad_buffer(geom, it.x.device)
-            K.conv_wgrad(geom, it.x, it.dz, raw, use_tr_read=use_tr_read)
-            K.wgrad_finalize(raw, convs[0].weight.detach(), it.a.st.scale, it.a.st.rstd, it.u.bn.running_mean, it.gsum, Cin, dws[0],
-                             dgamma=dgs[0], dbeta=dbs[0], dot=dots[0])
-        else:
-            slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
-            K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
-                                     [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
-                                     dws, dgs, dbs, dots, Cin)
+        # (single layers take the same path: its finalize folds deferred column sums, the stand-alone one does not)
+        slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
+        pending = sum(1 for it in items if isinstance(it.gsum, K.PartialColsum) and it.gsum._vec is None)
+        gsums = K.fold_partial_batched([it.gsum for it in items], zeros=take((pending, geom.K)) if pending else None)
+        K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
+                                 [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], gsums,
+                                 dws, dgs, dbs, dots, Cin)
         for it, dw, dg, db in zip(items, dws, dgs, dbs):
             emit(it.ui, "weight", dw)
             if need(it.ui, "gamma"):
@@ -521,7 +517,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             elif want_w or want_b or (want_bn and not a.train):
                 gsum = None
                 if want_b or (want_bn and not a.train):
-                    gsum = gsum_cache.pop(u.dst, None) if not a.train else None
+                    gsum = K.colsum_vector(gsum_cache.pop(u.dst, None)) if not a.train else None
                     if gsum is None:
                         gsum = K.colsum(dz)
                     if not a.train and u.res is not None and grads.get(u.res) is g:
@@ -557,11 +553,15 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 final = left[u.src] == 0
                 pending = grads.pop(u.src, None)
                 mask = x if (u.src in plan.relu_slots and final) else None
-                cs = take((geom.C,)) if final else None
-                dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs, grouped=u.grouped)
-                grads[u.src] = dx
                 if final:
-                    gsum_cache[u.src] = cs
+                    # column sums of the finished gradient feed its producer's BN/bias gradients: left as per-workgroup partial
+                    # rows where the launch allows it (the batched finalize folds them; one small launch less per layer)
+                    cs = take((geom.C,)) if (geom.stride != 1 or u.grouped) else None
+                    dx, gsum_cache[u.src] = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs, grouped=u.grouped,
+                                                         defer_colsum=True)
+                else:
+                    dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, grouped=u.grouped)
+                grads[u.src] = dx
         elif u.kind == "dw":
             if not a.train:
                 raise NotImplementedError(f"{u.name}: backward through an eval-mode depthwise block is not supported")

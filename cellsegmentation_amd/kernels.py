@@ -154,6 +154,7 @@ class LaunchTimer:
 
     def __init__(self):
         self.records = []      # (kind, geom tuple, dtype, start, end)
+        self.enabled = True    # the caller may switch the bracketing off for some steps
 
     def __enter__(self):
         global _timer
@@ -174,7 +175,7 @@ _timer = None
 
 def _timed(kind, geom, dtype, fn, extra_tensors=0, batch=1):
     """extra_tensors: how many destination-shaped tensors the epilogue also reads (residual / add / mask)."""
-    if _timer is None:
+    if _timer is None or not _timer.enabled:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -237,14 +238,60 @@ def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_
     return y
 
 
-def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False):
+class PartialColsum:
+    """Column sums of a dgrad output still in per-workgroup partial rows (cs_conv2d_dgrad with colsum == NULL): the batched
+    weight-gradient finalize folds them itself; vector() folds them now for any other consumer."""
+
+    def __init__(self, buf, rows, n_out):
+        self.buf, self.rows, self.n_out = buf, rows, n_out
+        self._vec = None
+
+    def vector(self):
+        if self._vec is None:
+            self._vec = torch.zeros((self.n_out,), dtype=torch.float32, device=self.buf.device)
+            _lib.check(_lib.load().cs_fold_partial_rows(_p(self.buf), self.rows, self.n_out, _p(self._vec), _stream()), "fold_partial_rows")
+        return self._vec
+
+
+def fold_partial_batched(gsums, zeros=None):
+    """[PartialColsum | vector] (n <= 8) -> [vector]: every pending fold of the list in ONE launch.
+    zeros: optional zero-filled fp32 [n_pending, n_out] scratch (allocated here when omitted)."""
+    pend = [g for g in gsums if isinstance(g, PartialColsum) and g._vec is None]
+    if pend:
+        n_out = pend[0].n_out
+        if any(g.n_out != n_out for g in pend):
+            raise ValueError("fold_partial_batched: mixed widths")
+        if zeros is None:
+            zeros = torch.zeros((len(pend), n_out), dtype=torch.float32, device=pend[0].buf.device)
+        arrp = (ctypes.c_void_p * len(pend))(*[g.buf.data_ptr() for g in pend])
+        arrr = (ctypes.c_int * len(pend))(*[g.rows for g in pend])
+        arro = (ctypes.c_void_p * len(pend))(*[zeros[i].data_ptr() for i in range(len(pend))])
+        _lib.check(_lib.load().cs_fold_partial_rows_batched(arrp, arrr, arro, len(pend), n_out, _stream()), "fold_partial_rows_batched")
+        for i, g in enumerate(pend):
+            g._vec = zeros[i]
+    return [g._vec if isinstance(g, PartialColsum) else g for g in gsums]
+
+
+def colsum_vector(g):
+    """A [C] fp32 tensor from either form of column sums."""
+    return g.vector() if isinstance(g, PartialColsum) else g
+
+
+def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False, defer_colsum=False):
+    """colsum: zeroed fp32 [C] to accumulate the column sums of dx into; or defer_colsum=True (stride 1, ungrouped) to get
+    (dx, PartialColsum) with the fold left to the consumer."""
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
     _mark_grouped(grouped)
-    ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if colsum is not None else None
+    defer = defer_colsum and geom.stride == 1 and not grouped
+    ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if (colsum is not None or defer) else None
     _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
-        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), _p(colsum), _p(ws), _stream()),
+        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), None if defer else _p(colsum), _p(ws), _stream()),
         extra_tensors=int(add is not None) + int(mask is not None)), "conv2d_dgrad")
+    if defer_colsum:
+        if defer:
+            return dx, PartialColsum(ws, lib.cs_conv2d_dgrad_partial_rows(ctypes.byref(geom)), geom.C)
+        return dx, colsum
     return dx
 
 
@@ -292,6 +339,8 @@ def wgrad_finalize_batched(slabs, ws, scales, rstds, means, gsums, dws, dgammas,
     def ptrs(lst):
         return [None] * n if lst is None else [t.data_ptr() for t in lst]
 
+    if gsums is not None and any(isinstance(g, PartialColsum) for g in gsums):
+        gsums = fold_partial_batched(gsums)
     flat = [slabs[i].data_ptr() for i in range(n)] + ptrs(ws) + ptrs(scales) + ptrs(rstds) + ptrs(means) + ptrs(gsums) + ptrs(dws) + \
         ptrs(dgammas) + ptrs(dbetas) + ptrs(dots)
     table = (ctypes.c_void_p * len(flat))(*flat)

@@ -131,6 +131,15 @@ int cs_set_igemm_path(int path);
  *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */
 int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                     const void* mask, void* dx, float* colsum, void* workspace, void* stream);
+/* Deferred column sums: with colsum == NULL and workspace != NULL (stride-1, ungrouped launches only) cs_conv2d_dgrad leaves the
+ * per-workgroup partial rows in `workspace` -- row r holds the sums of destination-pixel tile r at [r * 2*C + c] -- and skips the
+ * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows),
+ * cs_fold_partial_rows_batched n <= 8 of them (HOST pointer / row-count arrays, passed by value) in one launch -- the engine folds
+ * the buffers of a whole batched weight-gradient group together, right before its finalize. */
+int cs_conv2d_dgrad_partial_rows(const CsConvGeom* g);
+int cs_fold_partial_rows(const float* partial, int rows, int n_out, float* out, void* stream);
+int cs_fold_partial_rows_batched(const float* const* partial_tab, const int* rows_tab, float* const* out_tab, int n_items, int n_out,
+                                 void* stream);
 /* weight gradient, raw split-K partials: dw_khwc[nsplit][K][R][S][Cp] fp32, slab z = sum over pixel slice z of
  *   dy (x) im2col(x), written with plain stores (no zero-fill needed; nsplit = cs_conv2d_wgrad_splits(g, grouped));
  *   cs_wgrad_finalize folds the slabs in a fixed order (bitwise reproducible). */
