@@ -76,7 +76,11 @@ def kernel_name(kind, g, dtype):
     """Name of the kernel instantiation the C dispatcher picks for this launch (mirrors conv_igemm.hip)."""
     dt = "bf16" if dtype == torch.bfloat16 else "f32"
     if kind == "wgrad":
-        return f"wgrad_kernel<{dt},{128 if g['K'] > 64 else 64},128,{'true' if dt == 'bf16' else 'false'}>"     # TR: transposing LDS reads (bf16)
+        bm = 128 if g["K"] > 64 else 64
+        if dt == "bf16":      # LDS-DMA kernel: <BM, ring stages, PLAIN (1x1 / stride 1 / no padding), pixels per stage>
+            plain = g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0
+            return f"wgrad_dma_kernel<{bm}, 3, {'true' if plain else 'false'}, 32>"
+        return f"wgrad_kernel<{dt},{bm},128,false>"
     if kind == "fwd":
         M, nout, suffix = g["N"] * g["P"] * g["Q"], g["K"], ""
     else:

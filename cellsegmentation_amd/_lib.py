@@ -58,6 +58,8 @@ _SIGNATURES = {
     "cs_fold_partial_rows": (c_int, [_P, c_int, c_int, _P, _P]),
     "cs_wgrad_finalize_grouped": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "cs_colsum": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
+    "cs_colsum_partial_rows": (c_int, [c_longlong]),
+    "cs_colsum_partial": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_maxpool3x3s2_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_gap_avgmax_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),

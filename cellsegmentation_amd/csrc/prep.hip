@@ -272,7 +272,9 @@ __global__ void wgrad_finalize_b_kernel(const float* __restrict__ dot, const flo
 
 // ---- column sums: out[c] += sum_m g[m][c].  Thread owns 8 channels over a strided row set, the
 // workgroup folds its threads through LDS and issues ONE atomic per channel. ---------------------
-template <typename T>
+// PARTIAL: workgroup b stores its sums to out[b * 2*C + c] (the partial-row layout of cs_conv2d_dgrad) instead of adding them
+// to out[c]: ~512 atomics per address serialise at the memory side (~50 us on their own, whatever the streaming rate).
+template <typename T, bool PARTIAL>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, long long M, int C, float* __restrict__ out,
                                                      int rows_per_block) {
     const int CG = C / 8;
@@ -289,16 +291,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         if (rr < rpar) {
-            // four independent 16-byte loads in flight per thread (one dependent load per iteration streamed at 1.4 TB/s)
+            // eight independent 16-byte loads in flight per thread (one dependent load per iteration streamed at 1.4 TB/s)
             long long r = r0 + rr;
-            for (; r + 3LL * rpar < r1; r += 4LL * rpar) {
-                float v0[8], v1[8], v2[8], v3[8];
-                load8<T>(g + r * C + cg * 8, v0);
-                load8<T>(g + (r + rpar) * C + cg * 8, v1);
-                load8<T>(g + (r + 2LL * rpar) * C + cg * 8, v2);
-                load8<T>(g + (r + 3LL * rpar) * C + cg * 8, v3);
+            for (; r + 7LL * rpar < r1; r += 8LL * rpar) {
+                float v[8][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+                for (int u = 0; u < 8; ++u) load8<T>(g + (r + (long long)u * rpar) * C + cg * 8, v[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] += ((v[0][e] + v[1][e]) + (v[2][e] + v[3][e])) + ((v[4][e] + v[5][e]) + (v[6][e] + v[7][e]));
             }
             for (; r < r1; r += rpar) {
                 float v[8];
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
             for (int e = 0; e < 8; ++e) {
                 float t = 0.f;
                 for (int r = 0; r < rpar; ++r) t += fold[r * width + threadIdx.x][e];
-                atomicAdd(out + cg * 8 + e, t);
+                if constexpr (PARTIAL) out[(long long)blockIdx.x * 2 * C + cg * 8 + e] = t;
+                else atomicAdd(out + cg * 8 + e, t);
             }
         }
     }
@@ -474,18 +476,43 @@ extern "C" int cs_wgrad_finalize(const float* dw_khwc, int nsplit, int Kp, const
                            dbeta, dot_ws, accumulate, reinterpret_cast<hipStream_t>(stream));
 }
 
+static int colsum_rows_per_block(long long M) {
+    long long rows = (M + 511) / 512;
+    return (int)(rows < 64 ? 64 : rows);
+}
+
+extern "C" int cs_colsum_partial_rows(long long M) {
+    if (M <= 0) return 0;
+    const int rows = colsum_rows_per_block(M);
+    return (int)((M + rows - 1) / rows);
+}
+
+extern "C" int cs_colsum_partial(const void* g, int dtype, long long M, int C, float* partial, void* stream) {
+    CS_CHECK_ARG(g && partial, "colsum_partial: NULL tensor");
+    CS_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "colsum_partial: C must be a positive multiple of 8");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rows = colsum_rows_per_block(M);
+    const int blocks = (int)((M + rows - 1) / rows);
+    if (dtype == CS_F32) hipLaunchKernelGGL((colsum_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)g, M, C, partial, rows);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, M, C, partial, rows);
+    else CS_CHECK_ARG(false, "colsum_partial: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
 extern "C" int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream) {
     CS_CHECK_ARG(g && out, "colsum: NULL tensor");
     CS_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "colsum: C must be a positive multiple of 8");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // ~1024 workgroups (4 per CU), at least 64 rows each: <= 1024 atomics per channel
-    long long rows = (M + 1023) / 1024;
+    // ~512 workgroups (2 per CU), at least 64 rows each: <= 512 atomics per channel (1024 workgroups doubled the atomic
+    // contention on the few dozen addresses and ran 50 % slower)
+    long long rows = (M + 511) / 512;
     if (rows < 64) rows = 64;
     const int blocks = (int)((M + rows - 1) / rows);
     if (dtype == CS_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, M, C, out, (int)rows);
+        hipLaunchKernelGGL((colsum_kernel<float, false>), dim3(blocks), dim3(256), 0, st, (const float*)g, M, C, out, (int)rows);
     else if (dtype == CS_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, M, C, out, (int)rows);
+        hipLaunchKernelGGL((colsum_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, M, C, out, (int)rows);
     else
         CS_CHECK_ARG(false, "colsum: bad dtype");
     CS_LAUNCH_CHECK();

@@ -505,7 +505,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 # group: proportionally fewer partial slabs to write and fold)
                 gsum = gsum_cache.pop(u.dst, None)
                 if gsum is None:
-                    gsum = K.colsum(dz)
+                    gsum = K.colsum_partial(dz)
                 if u.res is not None and grads.get(u.res) is g:
                     gsum_cache[u.res] = gsum
                 key = _geom_key(geom)

@@ -180,6 +180,10 @@ int cs_wgrad_finalize_grouped(const float* dw_slab, int nsplit, const float* w, 
                               float* dbeta, float* dot_ws, void* stream);
 /* per-channel column sums: out[c] (+)= sum_m g[m][c]; fp32 out, zeroed by the caller. */
 int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* stream);
+/* The same sums left as per-workgroup partial rows (layout and consumers as for cs_conv2d_dgrad's deferred column sums):
+ * partial[b * 2*C + c], b < cs_colsum_partial_rows(M); no atomics, no zero-fill. */
+int cs_colsum_partial_rows(long long M);
+int cs_colsum_partial(const void* g, int dtype, long long M, int C, float* partial, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------
  * MaxPool2d(3, stride 2, pad 1) (resnet.py:114). */
