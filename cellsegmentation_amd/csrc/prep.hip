@@ -420,10 +420,56 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeT
         const int rs = i / Cin, c = i - rs * Cin;
         const long long src = ((long long)k * RS + rs) * Cp + c;
         float raw = 0.f;
+#pragma unroll 4
         for (int s = 0; s < nsplit; ++s) raw += raw_p[s * slab_stride + src];
         const long long o = (long long)k * per + c * RS + rs;
         if (want_dot) contrib = w[o] * raw;
         dw[o] = sc * raw;
+    }
+    if (want_dot) {
+        __shared__ float red[4];
+        contrib = wave_sum(contrib);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dot_s + k, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// R*S > 1: the slab layout is [k][rs][c] (c fastest), torch's is [k][c][rs] (rs fastest).  One thread per element either reads or
+// writes with a stride of R*S floats (every 64-byte line touched by R*S different waves); here a workgroup owns (k, 128 channels,
+// all taps), reads coalesced over c, turns the tile through LDS and writes 128*R*S CONTIGUOUS floats.
+constexpr int kFinCT = 128;
+__global__ __launch_bounds__(256) void wgrad_finalize_a_batched_tr_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit,
+                                                                          long long slab_stride, int want_dot) {
+    extern __shared__ float tile[];          // [RS][kFinCT + 1]
+    const int z = blockIdx.z, k = blockIdx.y, c0 = blockIdx.x * kFinCT;
+    const float* raw_s = nullptr; const float* w_s = nullptr; const float* sc_s = nullptr; float* dw_s = nullptr; float* dot_s = nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (z == i) { raw_s = t.raw[i]; w_s = t.w[i]; sc_s = t.scale[i]; dw_s = t.dw[i]; dot_s = t.dot[i]; }
+    const float* __restrict__ raw_p = raw_s;
+    const float* __restrict__ w = w_s;
+    float* __restrict__ dw = dw_s;
+    const float sc = t.has_scale ? sc_s[k] : 1.f;
+    const int cw = (Cin - c0) < kFinCT ? (Cin - c0) : kFinCT;       // channels of this tile
+    for (int idx = threadIdx.x; idx < RS * kFinCT; idx += 256) {
+        const int rs = idx / kFinCT, cl = idx - rs * kFinCT;
+        float raw = 0.f;
+        if (cl < cw) {
+            const long long src = ((long long)k * RS + rs) * Cp + c0 + cl;
+#pragma unroll 4
+            for (int s = 0; s < nsplit; ++s) raw += raw_p[s * slab_stride + src];
+        }
+        tile[rs * (kFinCT + 1) + cl] = raw;
+    }
+    __syncthreads();
+    float contrib = 0.f;
+    const long long obase = ((long long)k * Cin + c0) * RS;
+    for (int idx = threadIdx.x; idx < cw * RS; idx += 256) {
+        const int cl = idx / RS, rs = idx - cl * RS;
+        const float raw = tile[rs * (kFinCT + 1) + cl];
+        if (want_dot) contrib += w[obase + idx] * raw;
+        dw[obase + idx] = sc * raw;
     }
     if (want_dot) {
         __shared__ float red[4];
@@ -601,8 +647,12 @@ extern "C" int cs_wgrad_finalize_batched(const float* const* tables /* HOST: 10 
     t.has_scale = tables[2 * n_items] != nullptr;
     t.want_bn = want_bn;
     const int per = Cin * R * S;
-    hipLaunchKernelGGL(wgrad_finalize_a_batched_kernel, dim3((per + 255) / 256, K, n_items), dim3(256), 0, st, t, Cin, R * S, Cp, nsplit,
-                       (long long)Kp * R * S * Cp, want_bn);
+    if (R * S > 1 && R * S <= 64)
+        hipLaunchKernelGGL(wgrad_finalize_a_batched_tr_kernel, dim3((Cin + kFinCT - 1) / kFinCT, K, n_items), dim3(256),
+                           (size_t)R * S * (kFinCT + 1) * sizeof(float), st, t, Cin, R * S, Cp, nsplit, (long long)Kp * R * S * Cp, want_bn);
+    else
+        hipLaunchKernelGGL(wgrad_finalize_a_batched_kernel, dim3((per + 255) / 256, K, n_items), dim3(256), 0, st, t, Cin, R * S, Cp, nsplit,
+                           (long long)Kp * R * S * Cp, want_bn);
     CS_LAUNCH_CHECK();
     if (want_bn) {
         hipLaunchKernelGGL(wgrad_finalize_b_batched_kernel, dim3((K + 255) / 256, n_items), dim3(256), 0, st, t, K);
