@@ -97,6 +97,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 __device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned lds_base, unsigned voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
 }
+// the same with a scalar byte offset added to every lane's address (not part of the range check: `voff` alone decides
+// in / out of range) and a compile-time LDS displacement folded into the M0 write
+template <int LDS_IMM>
+__device__ __forceinline__ void dma16s(const i32x4& rsrc, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LDS_IMM) : "memory", "scc");
+}
 // workgroup barrier that neither drains the VM queue nor lets the compiler move LDS accesses across it
 __device__ __forceinline__ void dma_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
@@ -471,7 +478,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 //    registers before the K loop.  Multi-K-step launches hold 2 LDS stages = 2 workgroups per CU, so the register budget
 //    is 256 per wave anyway; without this the fat epilogue of the wide-output layers (2 operand reads + 1 write per
 //    output element) ran strictly after the K loop with nothing else in flight.
-template <typename T, int BM, int BN, int MODE, bool PF = false>
+//  * UNI (MODE 0 always; MODE 1 when the tap is the same for every lane of a K-step, i.e. C % 64 == 0, and R*S <= 32): the K walk
+//    lives in scalar registers.  Weights and MODE-0 pixels are fetched with a lane-constant voffset + a per-K-step scalar
+//    soffset (zero VALU per DMA); MODE-1 pixels add the tap offset and test one bit of a 32-bit validity mask (4 VALU per DMA).
+//    The lane-by-lane walk it replaces cost ~8 VALU + 6 SALU per MFMA (PMC), more issue slots than the MFMAs themselves.
+template <typename T, int BM, int BN, int MODE, bool PF = false, bool UNI = false>
 __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int ES = (int)sizeof(T);
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -605,6 +616,70 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
         }
     };
 
+    // ---- UNI: lane constants + scalar K walk -------------------------------------------------------------------------
+    unsigned voffA[AI], voffB[BI], vm32[AI];
+    int u_cc = 0, u_kh = 0, u_kw = 0, u_ks = 0;       // wave-uniform (scalar registers)
+    if constexpr (UNI) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            vm32[i] = (unsigned)vmask[i];
+            if constexpr (MODE == 0) voffA[i] = vmask[i] ? (unsigned)rbase[i] + (unsigned)lc * 16u : OOB;
+            else voffA[i] = (unsigned)rbase[i] + (unsigned)(lc + slab0) * 16u;      // may be "negative": the tap offset is added per lane
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) voffB[j] = bbase[j] != OOB ? bbase[j] + (unsigned)lc * 16u : OOB;
+    }
+    auto issue_uni = [&](int buf) {
+        const unsigned As = smem_base + (unsigned)buf * (STAGE * 16) + (unsigned)wave * 1024u;
+        const unsigned Bs = As + BM * 128;
+        const bool tail = (u_ks + 1) * 8 > p.Qtot;             // only MODE 0 with C % 64 != 0: some lanes' chunks do not exist
+        const unsigned lane_dead = (tail && (u_ks * 8 + lc) >= p.Qtot) ? OOB : 0u;
+        if constexpr (MODE == 0) {
+            const unsigned soff = (unsigned)u_ks * 128u;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const unsigned va = voffA[i] | lane_dead;
+                if (i == 0) dma16s<0>(rsrc_a, As, va, soff);
+                else if (i == 1) dma16s<4096>(rsrc_a, As, va, soff);
+                else if (i == 2) dma16s<8192>(rsrc_a, As, va, soff);
+                else dma16s<12288>(rsrc_a, As, va, soff);
+            }
+#pragma unroll
+            for (int j = 0; j < BI; ++j) {
+                const unsigned vb = voffB[j] | lane_dead;
+                if (j == 0) dma16s<0>(rsrc_b, Bs, vb, soff);
+                else if (j == 1) dma16s<4096>(rsrc_b, Bs, vb, soff);
+                else if (j == 2) dma16s<8192>(rsrc_b, Bs, vb, soff);
+                else dma16s<12288>(rsrc_b, Bs, vb, soff);
+            }
+        } else {
+            const unsigned toff = (unsigned)(((p.sgn * u_kh) * p.SW + p.sgn * u_kw) * p.SC * ES + u_cc * 16);
+            const unsigned bit = 1u << (u_kh * p.S + u_kw);
+            const unsigned soffB = (unsigned)(((p.wk0y + p.wkstep * u_kh) * p.S_full + p.wk0x + p.wkstep * u_kw) * p.SCc + u_cc) * 16u;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const unsigned va = (vm32[i] & bit) ? voffA[i] + toff : OOB;
+                if (i == 0) dma16s<0>(rsrc_a, As, va, 0u);
+                else if (i == 1) dma16s<4096>(rsrc_a, As, va, 0u);
+                else if (i == 2) dma16s<8192>(rsrc_a, As, va, 0u);
+                else dma16s<12288>(rsrc_a, As, va, 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < BI; ++j) {
+                if (j == 0) dma16s<0>(rsrc_b, Bs, voffB[j], soffB);
+                else if (j == 1) dma16s<4096>(rsrc_b, Bs, voffB[j], soffB);
+                else if (j == 2) dma16s<8192>(rsrc_b, Bs, voffB[j], soffB);
+                else dma16s<12288>(rsrc_b, Bs, voffB[j], soffB);
+            }
+            u_cc += 8;
+            if (u_cc >= p.SCc) {
+                u_cc = 0;
+                if (++u_kw == p.S) { u_kw = 0; ++u_kh; }
+            }
+        }
+        ++u_ks;
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -618,13 +693,17 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
     const int nk = (p.Qtot + 7) / 8;
     // both stages are requested up front (vmcnt retires in issue order: AI+BI outstanding = stage 0 has landed), then
     // stage ks+1 is re-requested into the buffer iteration ks-1 has finished reading
-    issue(0);
-    if (nk > 1) issue(1);
+    auto issue_any = [&](int buf) {
+        if constexpr (UNI) issue_uni(buf);
+        else issue(buf);
+    };
+    issue_any(0);
+    if (nk > 1) issue_any(1);
     for (int ks = 0; ks < nk; ++ks) {
         if (ks == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile ks have landed
         dma_barrier();                                      // ... and everybody else's; also frees the other buffer
-        if (ks >= 1 && ks + 1 < nk) issue((ks + 1) & 1);
+        if (ks >= 1 && ks + 1 < nk) issue_any((ks + 1) & 1);
         const uint4* As = smem + (ks & 1) * STAGE;
         const uint4* Bs = As + BM * 8;
 #pragma unroll
@@ -774,6 +853,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
 int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
                             // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
+const bool g_uni_walk = [] { const char* e = getenv("CELLSEG_NO_UNI"); return !(e && atoi(e)); }();   // A/B experiments only
 const bool g_epi_prefetch = [] { const char* e = getenv("CELLSEG_NO_EPI_PREFETCH"); return !(e && atoi(e)); }();   // A/B experiments only
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
 
@@ -825,13 +905,24 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
+    // scalar K walk: every 1x1 launch; tap-walking launches whose tap is wave-uniform (whole 64-element K-steps per tap)
+    const bool uni1 = g_uni_walk && mode == 1 && p.SCc % 8 == 0 && p.R * p.S <= 32;
+    const bool uni0 = g_uni_walk && mode == 0;
     if constexpr (sizeof(T) == 2) {
         if (dma && mode != 2 && nk_host > 1 && (p.residual || p.mask) && p.dst_step == 1 && g_epi_prefetch) {
-            if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+            if (mode == 0 && uni0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+            else if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+            else if (uni1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
             else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
             CS_LAUNCH_CHECK();
             return CS_OK;
         }
+    }
+    if (dma && ((mode == 0 && uni0) || uni1)) {
+        if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, false, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+        else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
     }
     if (dma) {
         switch (mode) {
@@ -855,7 +946,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 int igemm_tile(long long M, int NOUT) {
     static const int forced = [] { const char* e = getenv("CELLSEG_TILE"); return e ? atoi(e) : 0; }();   // experiments only
     if (forced) return (NOUT <= 64 && forced % 1000 == 128) ? forced - 64 : forced;
-    static const int thr = [] { const char* e = getenv("CELLSEG_TILE_THR"); return e ? atoi(e) : 384; }();   // experiments only
+    static const int thr = [] { const char* e = getenv("CELLSEG_TILE_THR"); return e ? atoi(e) : 1536; }();   // experiments only (A/B: 384..3072 within 1 %, 1536 best)
     const long long mt128 = (M + 127) / 128;
     if (NOUT > 64) {
         const long long blocks = mt128 * ((NOUT + 127) / 128);
