@@ -245,12 +245,23 @@ class PartialColsum:
     def __init__(self, buf, rows, n_out):
         self.buf, self.rows, self.n_out = buf, rows, n_out
         self._vec = None
+        self._vec_stream = None      # the stream the fold ran on (weight gradients may run on a side stream)
+
+    def _set(self, vec):
+        self._vec, self._vec_stream = vec, torch.cuda.current_stream()
+
+    def _sync(self):
+        cur = torch.cuda.current_stream()
+        if self._vec_stream is not None and cur != self._vec_stream:
+            cur.wait_stream(self._vec_stream)
+        return self._vec
 
     def vector(self):
         if self._vec is None:
-            self._vec = torch.zeros((self.n_out,), dtype=torch.float32, device=self.buf.device)
-            _lib.check(_lib.load().cs_fold_partial_rows(_p(self.buf), self.rows, self.n_out, _p(self._vec), _stream()), "fold_partial_rows")
-        return self._vec
+            vec = torch.zeros((self.n_out,), dtype=torch.float32, device=self.buf.device)
+            _lib.check(_lib.load().cs_fold_partial_rows(_p(self.buf), self.rows, self.n_out, _p(vec), _stream()), "fold_partial_rows")
+            self._set(vec)
+        return self._sync()
 
 
 def fold_partial_batched(gsums, zeros=None):
@@ -268,8 +279,8 @@ def fold_partial_batched(gsums, zeros=None):
         arro = (ctypes.c_void_p * len(pend))(*[zeros[i].data_ptr() for i in range(len(pend))])
         _lib.check(_lib.load().cs_fold_partial_rows_batched(arrp, arrr, arro, len(pend), n_out, _stream()), "fold_partial_rows_batched")
         for i, g in enumerate(pend):
-            g._vec = zeros[i]
-    return [g._vec if isinstance(g, PartialColsum) else g for g in gsums]
+            g._set(zeros[i])
+    return [g._sync() if isinstance(g, PartialColsum) else g for g in gsums]
 
 
 def colsum_vector(g):

@@ -32,13 +32,14 @@ _ALIGN = 64      # floats: every bucket slice starts on a 256-byte boundary
 
 
 class _Bucket:
-    __slots__ = ("flat", "items", "pending", "launched")
+    __slots__ = ("flat", "items", "pending", "launched", "streams")
 
     def __init__(self, n, device):
         self.flat = torch.zeros((n,), dtype=torch.float32, device=device)
         self.items = []          # (param, offset, numel)
         self.pending = 0
         self.launched = False
+        self.streams = set()     # streams whose kernels wrote gradients into this bucket since the last reduce()
 
 
 class GradReducer:
@@ -83,6 +84,7 @@ class GradReducer:
         for b in self.buckets:
             b.pending = len(b.items)
             b.launched = False
+            b.streams = set()
         self._overlap_ok = True
         self._delivered = set()
 
@@ -134,6 +136,8 @@ class GradReducer:
         view = b.flat[o:o + n].view_as(param)
         if grad.data_ptr() != view.data_ptr():
             view.copy_(grad)
+        if view.is_cuda:
+            b.streams.add(torch.cuda.current_stream())      # the engine finishes weight gradients on a side stream
         self._delivered.add(id(param))
         b.pending -= 1
         if b.pending == 0 and self._overlap_ok and self._layout_final:
@@ -147,6 +151,8 @@ class GradReducer:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
             self._stream.wait_stream(torch.cuda.current_stream())
+            for st in b.streams:
+                self._stream.wait_stream(st)
             with torch.cuda.stream(self._stream):
                 dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
                 b.flat.mul_(inv)
