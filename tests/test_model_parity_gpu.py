@@ -263,3 +263,50 @@ def test_one_launch_staging_equals_layer_by_layer(dev):
     o4, g4 = step(ref)                     # layer by layer on a fresh model
     assert float((o3 - o1).abs().max()) > 0
     assert torch.equal(o3, o4) and all(close(a, b) for a, b in zip(g3, g4))
+
+
+def test_full_size_bag_properties_bf16(dev):
+    """BASELINE.json's bench configuration (ResNet-50, bag of 64 tiles at 299x299, bf16, trainable trunk) is too large for the
+    CPU oracle, so it is checked through size-independent properties: tiles are independent (the logits of the bag equal the
+    logits of its quarters, bit for bit -- different M, tile shapes and grids, same per-element K order), and gradients are
+    additive over tiles (the bag's summed-loss gradients equal the sum over the quarters' up to bf16/split-K rounding)."""
+    from cellsegmentation_amd import synth
+    from cellsegmentation_amd.model import resnet as R
+
+    m = R.MILresnet50()
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    m = m.to(dev).set_compute_dtype(torch.bfloat16)
+    m.setmode("tile")
+    m.set_encoder_grads(True)
+    m.train()
+    x = synth.normalise(synth.ihc_tiles(8, 299, 4242)).repeat(8, 1, 1, 1)
+    x = (x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(7))).to(dev)      # 64 distinct tiles
+    y = torch.tensor([(3 * i + 1) % 2 for i in range(64)], device=dev)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+
+    def run(xs, ys):
+        for p in m.parameters():
+            p.grad = None
+        out = m(xs, freeze_bn=True)
+        torch.nn.functional.cross_entropy(out.float(), ys, reduction="sum").backward()
+        return out.detach().clone(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    o_full, g_full = run(x, y)
+    o_parts, g_sum = [], None
+    for q in range(4):
+        o, g = run(x[16 * q:16 * q + 16], y[16 * q:16 * q + 16])
+        o_parts.append(o)
+        g_sum = g if g_sum is None else {n: g_sum[n] + g[n] for n in g_sum}
+    assert torch.isfinite(o_full).all()
+    assert torch.equal(o_full, torch.cat(o_parts))
+    worst = 0.0
+    for n in names:
+        if n not in g_full:
+            continue
+        scale = float(g_sum[n].abs().max()) + 1e-12
+        worst = max(worst, float((g_full[n] - g_sum[n]).abs().max()) / scale)
+    # bf16 activations/gradients are rounded per tensor, so the two sides differ by rounding only where a sum is split differently
+    # (weight-gradient slices, column sums): a few bf16 ulps relative to each tensor's largest entry
+    assert worst < 2e-2, worst
