@@ -1655,7 +1655,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned 
 // every slice costs one extra write + read of the whole dW in fp32, so no more than needed to fill the chip
 int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
     const int tiles = cs_ceil_div(KO, BM) * cs_ceil_div(QE, 128) * (n_items > 1 ? n_items : 1);
-    long long want = (512 + tiles - 1) / tiles;
+    static const int target = [] { const char* e = getenv("CELLSEG_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();   // experiments only
+    long long want = (target + tiles - 1) / tiles;
     const long long max_split = (M + 63) / 64;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
