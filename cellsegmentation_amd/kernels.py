@@ -645,3 +645,50 @@ def segmented_topk(probs, groups, k_per_tile, seg_offsets, max_run):
     _lib.check(lib.cs_segmented_topk(_p(probs), _p(groups), _p(k_per_tile), _p(seg_offsets), seg_offsets.numel() - 1,
                                      int(max_run), T, _p(out), _p(cnt), _p(ws), ws_bytes, _stream()), "segmented_topk")
     return out, cnt
+
+
+# ---------------------------------------------------------------- either side of the top-k
+def segmented_order(probs, seg_offsets, max_run):
+    """np.lexsort((probs, groups)) for non-decreasing groups: int64 [T] on the device."""
+    T = probs.numel()
+    order = torch.empty((T,), dtype=torch.int64, device=probs.device)
+    _lib.check(_lib.load().cs_segmented_order(_p(probs), _p(seg_offsets), seg_offsets.numel() - 1, int(max_run), T, _p(order), _stream()),
+               "segmented_order")
+    return order
+
+
+def threshold_select(probs, order, threshold):
+    """order[probs[order] > threshold] -> (out_idx[T] int64, count[1] int64)."""
+    T = probs.numel()
+    lib = _lib.load()
+    ws_bytes = lib.cs_segmented_topk_workspace(T)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=probs.device)
+    out = torch.empty((T,), dtype=torch.int64, device=probs.device)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=probs.device)
+    _lib.check(lib.cs_threshold_select(_p(probs), _p(order), T, float(threshold), _p(out), _p(cnt), _p(ws), ws_bytes, _stream()), "threshold_select")
+    return out, cnt
+
+
+def evaluate_tile_counts(probs, order, groups, pos_from, threshold):
+    """int64 [4] on the device: #(pred != real), #(pred & !real), #(!pred & real), #real."""
+    counts = torch.zeros((4,), dtype=torch.int64, device=probs.device)
+    _lib.check(_lib.load().cs_evaluate_tile_counts(_p(probs), _p(order), _p(groups), _p(pos_from), float(threshold), probs.numel(), _p(counts),
+                                                   _stream()), "evaluate_tile_counts")
+    return counts
+
+
+def paint_tile_masks(selected, n_selected, groups, tile_xy, tile_size, n_images, H, W):
+    """uint8 [n_images, H, W] masks with a tile_size^2 block of ones per selected tile."""
+    masks = torch.zeros((n_images, H, W), dtype=torch.uint8, device=groups.device)
+    _lib.check(_lib.load().cs_paint_tile_masks(_p(selected) if n_selected else None, int(n_selected), _p(groups), _p(tile_xy), int(tile_size), H, W,
+                                               _p(masks), _stream()), "paint_tile_masks")
+    return masks
+
+
+def prune_excess(labels, flag, n_excess):
+    """Positions that survive deleting the first n_excess entries with labels == flag -> (kept[n] int64, count[1] int64)."""
+    n = labels.numel()
+    kept = torch.empty((n,), dtype=torch.int64, device=labels.device)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=labels.device)
+    _lib.check(_lib.load().cs_prune_excess(_p(labels), n, int(flag), int(n_excess), _p(kept), _p(cnt), _stream()), "prune_excess")
+    return kept, cnt

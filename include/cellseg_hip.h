@@ -280,6 +280,28 @@ int cs_segmented_topk(const float* probs, const int32_t* groups, const int32_t* 
                       const int64_t* seg_offsets, int n_groups, int max_run, long long T, int64_t* out_idx,
                       int64_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the steps either side of the top-k -----------------------------------------------------------
+ * cs_segmented_order: order = np.lexsort((probs, groups)) alone (train_seg.py:239, evaluate.py:13); order[T] int64.
+ * cs_threshold_select: order[[p > threshold for p in probs[order]]] (train_seg.py:243-245), i.e. `rank`'s tile list;
+ *   workspace as for cs_segmented_topk.
+ * cs_evaluate_tile_counts: evaluate.py:8-27 as four exact counts, counts4 (zeroed by the caller) += {pred != real,
+ *   pred & !real, !pred & real, real}; pos_from[g] (int64, host-computed, device-resident) = first sorted position labelled
+ *   positive for group g or any later group.
+ * cs_paint_tile_masks: utils/image_processing.py:92-98 -- masks[n_images][H][W] uint8 (zeroed by the caller) gets a
+ *   tile_size^2 block of ones at tile_xy[t] = (row, col) in image groups[t] for every t in selected[0..n_selected).
+ * cs_prune_excess: dataset/dataset.py:190-199 on the shuffled label array: positions kept when the first n_excess entries
+ *   with labels[i] == flag are deleted (kept[] int64 ascending, *kept_count). */
+int cs_segmented_order(const float* probs, const int64_t* seg_offsets, int n_groups, int max_run, long long T, int64_t* order,
+                       void* stream);
+int cs_threshold_select(const float* probs, const int64_t* order, long long T, float threshold, int64_t* out_idx,
+                        int64_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+int cs_evaluate_tile_counts(const float* probs, const int64_t* order, const int32_t* groups, const int64_t* pos_from,
+                            float threshold, long long T, unsigned long long* counts4, void* stream);
+int cs_paint_tile_masks(const int64_t* selected, long long n_selected, const int32_t* groups, const int32_t* tile_xy,
+                        int tile_size, int H, int W, uint8_t* masks, void* stream);
+int cs_prune_excess(const int32_t* labels, long long n, int flag, long long n_excess, int64_t* kept, int64_t* kept_count,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

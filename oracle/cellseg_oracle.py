@@ -358,3 +358,73 @@ def eff_forward(sd, x, arch, mode, training=True):
         return (F.linear(feat, sd["fc_image_cls.2.weight"], sd["fc_image_cls.2.bias"]),
                 torch.relu(F.linear(feat, sd["fc_image_reg.2.weight"], sd["fc_image_reg.2.bias"])))
     raise Exception("Something wrong in setmode.")
+
+
+# ---------------------------------------------------------------- either side of the top-k
+def make_train_data(tile_idx, tiles_grid, labels, idxs, pos_neg_ratio, perm):
+    """dataset/dataset.py:166-201 with `np.random.shuffle(self.train_data)` replaced by the explicit permutation `perm`
+    (position p of the shuffled array holds entry perm[p]).  Returns (rows [(tileIDX, x, y, label)], pos, neg)."""
+    train = [(int(tile_idx[i]), int(tiles_grid[i][0]), int(tiles_grid[i][1]), 0 if labels[tile_idx[i]] == 0 else 1) for i in idxs]
+    pos = sum(r[3] for r in train)
+    neg = len(train) - pos
+    train = [train[j] for j in perm]
+    if pos_neg_ratio is not None:
+        if pos > int(neg * pos_neg_ratio):
+            flag, n = 1, pos - int(neg * pos_neg_ratio)
+            pos = int(neg * pos_neg_ratio)
+        elif neg > int(pos / pos_neg_ratio):
+            flag, n = 0, neg - int(pos / pos_neg_ratio)
+            neg = int(pos / pos_neg_ratio)
+        else:
+            return np.asarray(train, dtype=np.int64).reshape(-1, 4), pos, neg
+        excess = []
+        for i, r in enumerate(train):
+            if r[3] == flag:
+                excess.append(i)
+            if len(excess) == n:
+                break
+        drop = set(excess)
+        train = [r for i, r in enumerate(train) if i not in drop]
+    return np.asarray(train, dtype=np.int64).reshape(-1, 4), pos, neg
+
+
+def evaluate_tile(tile_idx, labels, probs, tiles_per_pos, threshold):
+    """evaluate.py:8-27 + metrics/metrics.py:7-16 (calc_err)."""
+    groups = np.array(tile_idx)
+    probs = np.asarray(probs)
+    order = np.lexsort((probs, groups))
+    groups = groups[order]
+    p = probs[order]
+    pred = np.array([x > threshold for x in p])
+    real = np.zeros(len(p))
+    for i in range(1, len(p) + 1):
+        if i == len(p) or groups[i] != groups[i - 1]:
+            n = labels[groups[i - 1]] * tiles_per_pos
+            real[i - n: i] = [1] * n
+    neq = np.not_equal(pred, real)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        err = float(neq.sum()) / pred.shape[0]
+        fpr = float(np.logical_and(pred == 1, neq).sum()) / (real == 0).sum()
+        fnr = float(np.logical_and(pred == 0, neq).sum()) / (real == 1).sum()
+    return err, fpr, fnr
+
+
+def rank_tiles(tile_idx, tiles_grid, probs, threshold):
+    """The nested `rank` of train_seg.py:234-249."""
+    groups = np.array(tile_idx)
+    tiles = np.array(tiles_grid)
+    probs = np.asarray(probs)
+    order = np.lexsort((probs, groups))
+    groups, p, tiles = groups[order], probs[order], tiles[order]
+    index = [x > threshold for x in p]
+    return tiles[index], p[index], groups[index]
+
+
+def generate_masks(n_images, image_size, tile_size, tiles, groups):
+    """utils/image_processing.py:90-98 (square painting; no pre-processing, nothing saved).  Tiles lie inside the image
+    (dataset.get_tiles aligns the last row / column to the border); the reference's slice assignment fails otherwise."""
+    masks = np.zeros((n_images, *image_size)).astype(np.uint8)
+    for i in range(len(groups)):
+        x, y = int(tiles[i][0]), int(tiles[i][1])
+        masks[groups[i]][x: x + tile_size, y: y + tile_size] = np.ones((tile_size, tile_size)).astype(np.uint8)
+    return masks
