@@ -14,8 +14,10 @@ namespace {
 
 // Two per-thread partial sums for 8 channels -> one fp64 atomic per channel per workgroup.
 // Threads are laid out tid = rr*width + (cg - cg0); rows rr < rpar hold valid partials.
+// partial != NULL: the workgroup's two sums go to partial[(2*blockIdx.x + {0,1}) * C + c] with plain stores instead (folded by
+// bn_partial_fold_kernel): ~1000 fp64 atomics per address serialise at the memory side and cost more than the streaming pass.
 __device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const float (&b)[8], int width, int rpar, int cg, bool live,
-                                                  double* out0, double* out1) {
+                                                  double* out0, double* out1, double* partial = nullptr, int C = 0) {
     __shared__ float fold[2][256][8];
     __syncthreads();
 #pragma unroll
@@ -32,15 +34,20 @@ __device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const flo
                 t0 += (double)fold[0][r * width + threadIdx.x][e];
                 t1 += (double)fold[1][r * width + threadIdx.x][e];
             }
-            atomicAdd(out0 + cg * 8 + e, t0);
-            atomicAdd(out1 + cg * 8 + e, t1);
+            if (partial) {
+                partial[(2LL * blockIdx.x) * C + cg * 8 + e] = t0;
+                partial[(2LL * blockIdx.x + 1) * C + cg * 8 + e] = t1;
+            } else {
+                atomicAdd(out0 + cg * 8 + e, t0);
+                atomicAdd(out1 + cg * 8 + e, t1);
+            }
         }
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, long long M, int C, double* __restrict__ stats,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, double* __restrict__ partial) {
     const int CG = C / 8;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
@@ -55,14 +62,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
         if (live) {
-            for (long long r = r0 + rr; r < r1; r += rpar) {
+            long long r = r0 + rr;
+            for (; r + 3LL * rpar < r1; r += 4LL * rpar) {            // four independent 16-byte loads in flight per thread
+                float v[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load8<T>(z + (r + (long long)u * rpar) * C + cg * 8, v[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+                    s2[e] += (v[0][e] * v[0][e] + v[1][e] * v[1][e]) + (v[2][e] * v[2][e] + v[3][e] * v[3][e]);
+                }
+            }
+            for (; r < r1; r += rpar) {
                 float v[8];
                 load8<T>(z + r * C + cg * 8, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
             }
         }
-        block_fold_atomic(s1, s2, width, rpar, cg, live, stats, stats + C);
+        block_fold_atomic(s1, s2, width, rpar, cg, live, stats, stats + C, partial, C);
     }
 }
 
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                             long long M, int C, double* __restrict__ sums,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, double* __restrict__ partial) {
     const int CG = C / 8;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 }
             }
         }
-        block_fold_atomic(s0, s1, width, rpar, cg, live, sums, sums + C);
+        block_fold_atomic(s0, s1, width, rpar, cg, live, sums, sums + C, partial, C);
     }
 }
 
@@ -206,6 +224,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// out[j] += sum_b partial[b][j] for the 2*C columns of the per-workgroup partial sums; gridDim.y row chunks -> <= 8 atomics per address
+__global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __restrict__ partial, int blocks, int cols, double* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const int per = (blocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per;
+    int b1 = b0 + per;
+    if (b1 > blocks) b1 = blocks;
+    double acc = 0.0;
+    for (int b = b0; b < b1; ++b) acc += partial[(long long)b * cols + j];
+    if (b0 < blocks) atomicAdd(out + j, acc);
+}
+
+inline int fold_partial(const double* partial, int blocks, int C, double* out, hipStream_t st) {
+    int chunks = blocks / 128;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 8) chunks = 8;
+    hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((2 * C + 255) / 256, chunks), dim3(256), 0, st, partial, blocks, 2 * C, out);
+    return 0;
+}
+
 inline int rows_per_block_for(long long M) {
     long long r = (M + 1023) / 1024;
     if (r < 64) r = 64;
@@ -226,16 +265,26 @@ inline int grid_ew(long long total) {
     else if (dtype == CS_BF16) { CALL_BF16; }                \
     else { cs_set_error_(NAME ": bad dtype"); return CS_ERR_INVALID_ARG; }
 
-extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, void* stream) {
+extern "C" size_t cs_bn_partial_workspace(long long M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    const int rpb = rows_per_block_for(M);
+    return (size_t)((M + rpb - 1) / rpb) * 2 * (size_t)C * sizeof(double);
+}
+
+extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream) {
     CS_CHECK_ARG(z && stats && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rpb = rows_per_block_for(M);
     const int blocks = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, M, C, stats, rpb),
-                  hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, M, C, stats, rpb),
+                  hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, M, C, stats, rpb, workspace),
+                  hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, M, C, stats, rpb, workspace),
                   "bn_stats");
     CS_LAUNCH_CHECK();
+    if (workspace) {
+        fold_partial(workspace, blocks, C, stats, st);
+        CS_LAUNCH_CHECK();
+    }
     return CS_OK;
 }
 
@@ -265,18 +314,23 @@ extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const fl
 }
 
 extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
-                                const float* gamma, const float* beta, int act, long long M, int C, double* sums, void* stream) {
+                                const float* gamma, const float* beta, int act, long long M, int C, double* sums, double* workspace,
+                                void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rpb = rows_per_block_for(M);
     const int blocks = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
-                                     rstd, gamma, beta, act, M, C, sums, rpb),
+                                     rstd, gamma, beta, act, M, C, sums, rpb, workspace),
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z,
-                                     mean, rstd, gamma, beta, act, M, C, sums, rpb),
+                                     mean, rstd, gamma, beta, act, M, C, sums, rpb, workspace),
                   "bn_bwd_reduce");
     CS_LAUNCH_CHECK();
+    if (workspace) {
+        fold_partial(workspace, blocks, C, sums, st);
+        CS_LAUNCH_CHECK();
+    }
     return CS_OK;
 }
 

@@ -41,7 +41,9 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream; ~10x cheaper than building a torch.cuda.Stream object per launch (the
+    # BN-train image path issues ~1000 launches per step and is host-bound)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def make_geom(N, H, W, C, K, R, S, stride, pad):
@@ -402,8 +404,15 @@ def bn_stats(z, stats=None):
     M = z.numel() // C
     if stats is None:
         stats = new_stats(C, z.device)
-    _lib.check(_lib.load().cs_bn_stats(_p(z), _code(z.dtype), M, C, _p(stats), _stream()), "bn_stats")
+    _lib.check(_lib.load().cs_bn_stats(_p(z), _code(z.dtype), M, C, _p(stats), _p(_bn_ws(M, C, z.device)), _stream()), "bn_stats")
     return stats
+
+
+def _bn_ws(M, C, device):
+    """Partial-sum workspace of the BN reductions (None for small row counts: a few workgroups, atomics are fine)."""
+    if M < 16384:
+        return None
+    return torch.empty((_lib.load().cs_bn_partial_workspace(M, C) // 8,), dtype=torch.float64, device=device)
 
 
 def bn_finalize(stats, M, eps, momentum, running_mean=None, running_var=None):
@@ -429,7 +438,8 @@ def bn_bwd(dy, z, mean, rstd, gamma, want_param_grads=True, beta=None, act=CS_AC
     M = z.numel() // C
     sums = new_stats(C, z.device)
     lib = _lib.load()
-    _lib.check(lib.cs_bn_bwd_reduce(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(beta), act, M, C, _p(sums), _stream()), "bn_bwd_reduce")
+    _lib.check(lib.cs_bn_bwd_reduce(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(beta), act, M, C, _p(sums),
+                                    _p(_bn_ws(M, C, z.device)), _stream()), "bn_bwd_reduce")
     dz = torch.empty_like(z)
     dg = torch.empty((2, C), dtype=torch.float32, device=z.device) if want_param_grads else None
     _lib.check(lib.cs_bn_bwd_apply(_p(dy), _p(z), _code(z.dtype), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _p(sums), M, C, _p(dz),

@@ -42,3 +42,4 @@ timeit("torch sum (r)", lambda: x.sum(), nbytes)
 x4 = torch.randn((N, H, W, 64), device=dev).to(torch.bfloat16)
 timeit("torch repeat 1->4 (r/4 + w)", lambda: torch.cat([x4, x4, x4, x4], dim=-1, out=y), 1.25 * nbytes)
 timeit("cs colsum_partial + fold (r)", lambda: K.colsum_partial(x).vector(), nbytes)
+timeit("cs bn_stats (r)", lambda: K.bn_stats(x), nbytes)
