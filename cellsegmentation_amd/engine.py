@@ -239,6 +239,22 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             packs.pop(dtype, None)
             record = []
 
+    # train-mode BN bookkeeping for the whole plan in two launches instead of two per layer: one zero-filled fp64 arena for the
+    # per-channel statistics, one foreach-add for the num_batches_tracked counters (this path is host-bound: ~1000 launches/step)
+    stats_arena, stats_pos, bumped = None, [0], []
+    if bn_train:
+        need = sum(2 * K.pad_channels(u_.conv.out_channels) for u_ in plan.units
+                   if u_.kind == "conv" and _bn_uses_batch_stats(u_.bn, bn_train))
+        if need:
+            stats_arena = torch.zeros((need,), dtype=torch.float64, device=t[plan.inputs[0]].device)
+
+    def take_stats(C):
+        if stats_arena is None or stats_pos[0] + 2 * C > stats_arena.numel():
+            return K.new_stats(C, t[plan.inputs[0]].device)
+        v = stats_arena[stats_pos[0]:stats_pos[0] + 2 * C].view(2, C)
+        stats_pos[0] += 2 * C
+        return v
+
     for ui, u in enumerate(plan.units):
         if u.kind == "conv":
             x = t[u.src]
@@ -266,14 +282,14 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=False)
             else:
                 bn = u.bn
-                stats = K.new_stats(Kp, x.device)
+                stats = take_stats(Kp)
                 z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats, grouped=u.grouped)
                 M = N * geom.P * geom.Q
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 mean, rstd = K.bn_finalize(stats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
                                            bn.running_var if bn.track_running_stats else None)
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
+                    bumped.append(bn.num_batches_tracked)
                 y = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), res, u.act)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=True, z=z if save else None, mean=mean, rstd=rstd)
             t[u.dst] = y
@@ -291,7 +307,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 mean, rstd = K.bn_finalize(K.bn_stats(z), M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
                                            bn.running_var if bn.track_running_stats else None)
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
+                    bumped.append(bn.num_batches_tracked)
                 t[u.dst] = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), None, u.act)
                 aux[ui] = SimpleNamespace(geom=geom, train=True, z=z if save else None, mean=mean, rstd=rstd, w_hwc=w_hwc)
             else:
@@ -331,6 +347,8 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             aux[ui] = SimpleNamespace(ca=a.shape[-1])
         for s in u.inputs():
             release(s)
+    if bumped:
+        torch._foreach_add_(bumped, 1)
     if record:
         pk = K.StagePack([(conv_, bn_, cp_, kp_, nb_) for _, conv_, bn_, cp_, kp_, nb_ in record], dtype)
         pk.by_unit = {}
