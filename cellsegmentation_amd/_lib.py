@@ -92,6 +92,12 @@ _SIGNATURES = {
     "cs_softmax_channel_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_longlong, c_int, _P]),
     "cs_segmented_topk_workspace": (c_size_t, [c_longlong]),
     "cs_segmented_topk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_longlong, _P, _P, _P, c_size_t, _P]),
+    "cs_stem_pair_input": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "cs_stem_pair_weights": (c_int, [_P, c_int, c_int, _P, _P]),
+    "cs_stem_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "cs_stem_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int]),
+    "cs_stem_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "cs_stem_unpair_slabs": (c_int, [_P, c_int, c_int, _P, _P]),
     "cs_segmented_order": (c_int, [_P, _P, c_int, c_int, c_longlong, _P, _P]),
     "cs_threshold_select": (c_int, [_P, _P, c_longlong, c_float, _P, _P, _P, c_size_t, _P]),
     "cs_evaluate_tile_counts": (c_int, [_P, _P, _P, _P, c_float, c_longlong, _P, _P]),

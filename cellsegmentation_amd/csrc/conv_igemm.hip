@@ -39,6 +39,7 @@ struct IgemmParams {
     int NOUT;         // destination channels
     int R, S;
     int mul, div, off0, off0x, sgn;   // off0 = y offset, off0x = x offset
+    int mulx;         // x stride of the source walk (== mul except for the pixel-paired stem: rows stride 2, pixel pairs stride 1)
     int act;
     // weight-tap walk: filter tap of loop tap (kh,kw) = (wk0y + wkstep*kh, wk0x + wkstep*kw) in an S_full-wide filter
     int wk0y, wk0x, wkstep, S_full;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                 const int dy = rem / p.DW;
                 const int dx = rem - dy * p.DW;
                 const int y0 = dy * p.mul + p.off0;
-                const int x0 = dx * p.mul + p.off0x;
+                const int x0 = dx * p.mulx + p.off0x;
                 if constexpr (MODE == 1) {
                     rbase[i] = ((img * p.SH + y0) * (long long)p.SW + x0) * p.SC;
                     unsigned long long mk = 0;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
                 const int dy = rem / p.DW;
                 const int dx = rem - dy * p.DW;
                 const int y0 = dy * p.mul + p.off0;
-                const int x0 = dx * p.mul + p.off0x;
+                const int x0 = dx * p.mulx + p.off0x;
                 if constexpr (MODE == 1) {
                     rbase[i] = (int)(((img * p.SH + y0) * (long long)p.SW + x0) * p.SC * ES);
                     unsigned long long mk = 0;
@@ -859,7 +860,7 @@ int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always registe
 
 int igemm_mode(const IgemmParams& p) {
     if (p.div > 1) return 2;
-    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.off0 == 0 && p.off0x == 0 && p.wkstep == 1 && p.dst_step == 1 && !p.cslab) return 0;
+    if (p.R == 1 && p.S == 1 && p.mul == 1 && p.mulx == 1 && p.off0 == 0 && p.off0x == 0 && p.wkstep == 1 && p.dst_step == 1 && !p.cslab) return 0;
     return p.R * p.S <= 64 ? 1 : 2;
 }
 
@@ -1029,7 +1030,7 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     p.SH = g->H; p.SW = g->W; p.SC = g->C;
     p.DH = g->P; p.DW = g->Q; p.NOUT = g->K;
     p.R = g->R; p.S = g->S;
-    p.mul = g->stride; p.div = 1; p.off0 = -g->pad; p.off0x = -g->pad; p.sgn = 1;
+    p.mul = g->stride; p.mulx = g->stride; p.div = 1; p.off0 = -g->pad; p.off0x = -g->pad; p.sgn = 1;
     p.wk0y = 0; p.wk0x = 0; p.wkstep = 1; p.S_full = g->S;
     p.dst_step = 1; p.dst_oy = 0; p.dst_ox = 0; p.DHF = g->P; p.DWF = g->Q;
     p.act = act;
@@ -1127,7 +1128,7 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     p.SH = g->P; p.SW = g->Q; p.SC = g->K;
     p.DH = g->H; p.DW = g->W; p.NOUT = g->C;
     p.R = g->R; p.S = g->S;
-    p.mul = 1; p.div = g->stride; p.off0 = g->pad; p.off0x = g->pad; p.sgn = -1;
+    p.mul = 1; p.mulx = 1; p.div = g->stride; p.off0 = g->pad; p.off0x = g->pad; p.sgn = -1;
     p.wk0y = 0; p.wk0x = 0; p.wkstep = 1; p.S_full = g->S;
     p.dst_step = 1; p.dst_oy = 0; p.dst_ox = 0; p.DHF = g->H; p.DWF = g->W;
     p.act = CS_ACT_NONE;
@@ -1155,7 +1156,7 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
             c.DH = (g->H - py + sd - 1) / sd;
             c.DW = (g->W - px + sd - 1) / sd;
             if (c.DH <= 0 || c.DW <= 0) continue;
-            c.div = 1; c.mul = 1; c.sgn = -1;
+            c.div = 1; c.mul = 1; c.mulx = 1; c.sgn = -1;
             c.off0 = (py + g->pad - kh0) / sd;
             c.off0x = (px + g->pad - kw0) / sd;
             c.R = nj; c.S = ni;
@@ -1189,6 +1190,7 @@ struct WgradParams {
     int P, Q;
     int KO;
     int R, S, stride, pad;
+    int stride_x, pad_x;   // == stride, pad except for the pixel-paired stem
     long long M;
     int QE;           // R*S*Cq (elements of one dW row)
     int Cq;           // channels per tap in dW's K space: C, or 64 for slab-dense grouped convolution
@@ -1305,7 +1307,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (b_ok && m < mend) {
                 const int iy = boy[i] * p.stride - p.pad + b_kh;
-                const int ix = box[i] * p.stride - p.pad + b_kw;
+                const int ix = box[i] * p.stride_x - p.pad_x + b_kw;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                     const long long pix = (bn_[i] * p.H + iy) * (long long)p.W + ix;
                     v = *reinterpret_cast<const uint4*>(xs + pix * p.C + b_c);
@@ -1529,7 +1531,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned 
     const unsigned mend32 = (unsigned)mend;
     const unsigned x_row_b = (unsigned)p.C * 2u;
     const unsigned b_col = (unsigned)b_c * 2u;
-    const int b_dy = b_kh - p.pad, b_dx = b_kw - p.pad;
+    const int b_dy = b_kh - p.pad, b_dx = b_kw - p.pad_x;
 
     auto issue = [&](int buf) {
         const unsigned As = smem_base + (unsigned)buf * STAGE;
@@ -1556,7 +1558,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned 
                 const unsigned w2 = __umulhi(u, magicP);
                 const unsigned oy = u - w2 * (unsigned)p.P;
                 const int iy = (int)oy * p.stride + b_dy;
-                const int ix = (int)ox * p.stride + b_dx;
+                const int ix = (int)ox * p.stride_x + b_dx;
                 if (b_ok && m < mend32 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
                     vb = (((img0 + w2) * (unsigned)p.H + (unsigned)iy) * (unsigned)p.W + (unsigned)ix) * x_row_b + b_col;
             }
@@ -1734,7 +1736,7 @@ extern "C" int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const voi
     p.n_items = n_items;
     p.H = g->H; p.W = g->W; p.C = g->C;
     p.P = g->P; p.Q = g->Q; p.KO = g->K;
-    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
+    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.stride_x = g->stride; p.pad_x = g->pad;
     p.M = (long long)g->N * g->P * g->Q;
     p.Cq = g->C; p.slab = 0;
     p.QE = g->R * g->S * p.Cq;
@@ -1759,7 +1761,7 @@ extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     p.x = x; p.dy = dy; p.dw = dw_khwc;
     p.H = g->H; p.W = g->W; p.C = g->C;
     p.P = g->P; p.Q = g->Q; p.KO = g->K;
-    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
+    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.stride_x = g->stride; p.pad_x = g->pad;
     p.M = (long long)g->N * g->P * g->Q;
     p.Cq = slab ? 64 : g->C;
     p.slab = slab;
@@ -1777,4 +1779,154 @@ extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     }
     if (wide) return launch_wgrad<bf16_t, 128, 128, false>(p, st);
     return launch_wgrad<bf16_t, 64, 128, false>(p, st);
+}
+
+// =============================================================================================
+// Stem on a pixel-PAIRED image (7x7 / stride 2 / pad 3, 3 input channels: model/resnet.py:111).
+// With the 3 channels padded to one 16-byte chunk per pixel the implicit GEMM walks 49 chunks of which 147/392 elements are
+// real: 2.7x the MFMA work and DMA count of the arithmetic.  Storing TWO neighbouring pixels x 4 channels per chunk turns the
+// layer into a 7x4-tap convolution over [N][H][ceil(W/2)][8] with row stride 2, pair stride 1, pad (3, 2): 28 chunks, 147/224
+// real.  Output pixel px reads pairs px-2 .. px+1 = pixels 2px-4 .. 2px+3; tap (kh, kw') element e holds filter column
+// kw = 2*kw' - 1 + e/4 (kw = -1: zero) and channel e % 4 (channel 3: zero).  Same igemm / weight-gradient kernels, two
+// extra parameters (x stride / x pad); three tiny kernels convert the image, the staged weights and the raw gradient.
+// =============================================================================================
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pair_input_kernel(const T* __restrict__ x, int N, int H, int W, int Wh, T* __restrict__ out) {
+    // one thread per output chunk: out[n][h][j][0..7] = {x[n][h][2j][0..3], x[n][h][2j+1][0..3]}
+    const long long total = (long long)N * H * Wh;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % Wh);
+        const long long nh = idx / Wh;
+        const T* src = x + (nh * W + 2 * j) * 8;
+        T v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = src[e];
+            v[4 + e] = (2 * j + 1 < W) ? src[8 + e] : from_f32<T>(0.f);
+        }
+        v[3] = from_f32<T>(0.f); v[7] = from_f32<T>(0.f);
+        T* dst = out + idx * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = v[e];
+    }
+}
+
+template <typename T>
+__global__ void stem_pair_weights_kernel(const T* __restrict__ w /*[K][7][7][8]*/, int K, T* __restrict__ out /*[K][7][4][8]*/) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= K * 7 * 4 * 8) return;
+    const int e = idx & 7, kwp = (idx >> 3) & 3, kh = (idx >> 5) % 7, k = idx / (32 * 7);
+    const int kw = 2 * kwp - 1 + (e >> 2), c = e & 3;
+    out[idx] = (kw >= 0 && kw < 7 && c < 3) ? w[((k * 7 + kh) * 7 + kw) * 8 + c] : from_f32<T>(0.f);
+}
+
+// raw paired slabs [nsplit][K][7][4][8] -> one slab in the ordinary [K][7][7][8] layout (splits summed, padding lanes dropped)
+__global__ void stem_unpair_slabs_kernel(const float* __restrict__ slabs, int nsplit, int K, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= K * 49 * 8) return;
+    const int c = idx & 7, kw = (idx >> 3) % 7, kh = (idx / 56) % 7, k = idx / 392;
+    float v = 0.f;
+    if (c < 3) {
+        const int kwp = (kw + 1) >> 1, e = 4 * ((kw + 1) & 1) + c;
+        const long long src = ((long long)(k * 7 + kh) * 4 + kwp) * 8 + e;
+        for (int s = 0; s < nsplit; ++s) v += slabs[(long long)s * K * 224 + src];
+    }
+    out[idx] = v;
+}
+
+}  // namespace
+
+extern "C" int cs_stem_pair_input(const void* x_nhwc8, int dtype, int N, int H, int W, void* x_pair, void* stream) {
+    CS_CHECK_ARG(x_nhwc8 && x_pair && N > 0 && H > 0 && W > 0, "stem_pair_input: bad arguments");
+    const int Wh = (W + 1) / 2;
+    const long long total = (long long)N * H * Wh;
+    long long nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CS_F32) hipLaunchKernelGGL(stem_pair_input_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)x_nhwc8, N, H, W, Wh, (float*)x_pair);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(stem_pair_input_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)x_nhwc8, N, H, W, Wh, (bf16_t*)x_pair);
+    else CS_CHECK_ARG(false, "stem_pair_input: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_stem_pair_weights(const void* w_khwc, int dtype, int K, void* w_pair, void* stream) {
+    CS_CHECK_ARG(w_khwc && w_pair && K > 0, "stem_pair_weights: bad arguments");
+    const int total = K * 7 * 4 * 8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CS_F32) hipLaunchKernelGGL(stem_pair_weights_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)w_khwc, K, (float*)w_pair);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(stem_pair_weights_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)w_khwc, K, (bf16_t*)w_pair);
+    else CS_CHECK_ARG(false, "stem_pair_weights: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_stem_fwd(int N, int H, int W, int K, int dtype, const void* x_pair, const void* w_pair, const float* scale,
+                           const float* shift, int act, void* y, double* stats, void* workspace, void* stream) {
+    CS_CHECK_ARG(x_pair && w_pair && y && N > 0 && H >= 7 && W >= 7 && K > 0 && K % 8 == 0, "stem_fwd: bad arguments");
+    CS_CHECK_ARG(dtype == CS_F32 || dtype == CS_BF16, "stem_fwd: bad dtype");
+    CS_CHECK_ARG(!stats || workspace, "stem_fwd: stats need a workspace of cs_conv2d_stats_workspace() bytes");
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1, Wh = (W + 1) / 2;
+    IgemmParams p{};
+    p.src = x_pair; p.wgt = w_pair; p.dst = y;
+    p.scale = scale; p.shift = shift; p.residual = nullptr; p.mask = nullptr;
+    p.slab = stats ? reinterpret_cast<float*>(workspace) : nullptr;
+    p.SH = H; p.SW = Wh; p.SC = 8;
+    p.DH = P; p.DW = Q; p.NOUT = K;
+    p.R = 7; p.S = 4;
+    p.mul = 2; p.mulx = 1; p.div = 1; p.off0 = -3; p.off0x = -2; p.sgn = 1;
+    p.wk0y = 0; p.wk0x = 0; p.wkstep = 1; p.S_full = 4;
+    p.dst_step = 1; p.dst_oy = 0; p.dst_ox = 0; p.DHF = P; p.DWF = Q;
+    p.act = act;
+    p.M = (long long)N * P * Q;
+    p.src_pixels = (long long)N * H * Wh;
+    p.SCc = 8 / ce;
+    p.cslab = 0;
+    p.Qtot = 7 * 4 * p.SCc;
+    p.wrow_chunks = p.Qtot;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == CS_F32 ? dispatch_igemm<float>(p, nullptr, stats, st) : dispatch_igemm<bf16_t>(p, nullptr, stats, st);
+}
+
+static void stem_wgrad_params(WgradParams& p, int N, int H, int W, int K, int dtype) {
+    const int ce = dtype == CS_F32 ? 4 : 8;
+    p.H = H; p.W = (W + 1) / 2; p.C = 8;
+    p.P = (H + 6 - 7) / 2 + 1; p.Q = (W + 6 - 7) / 2 + 1; p.KO = K;
+    p.R = 7; p.S = 4; p.stride = 2; p.pad = 3; p.stride_x = 1; p.pad_x = 2;
+    p.M = (long long)N * p.P * p.Q;
+    p.Cq = 8; p.slab = 0;
+    p.QE = 7 * 4 * 8;
+    p.SCc = 8 / ce;
+}
+
+extern "C" int cs_stem_wgrad_splits(int N, int H, int W, int K) {
+    if (N <= 0 || H < 7 || W < 7 || K <= 0) return 0;
+    const long long M = (long long)N * ((H + 6 - 7) / 2 + 1) * ((W + 6 - 7) / 2 + 1);
+    return wgrad_splits(M, K, 224, K > 64 ? 128 : 64);
+}
+
+extern "C" int cs_stem_wgrad(int N, int H, int W, int K, int dtype, const void* x_pair, const void* dy, float* dw_pair_slabs,
+                             int use_tr_read, void* stream) {
+    CS_CHECK_ARG(x_pair && dy && dw_pair_slabs && N > 0 && H >= 7 && W >= 7 && K > 0 && K % 8 == 0, "stem_wgrad: bad arguments");
+    CS_CHECK_ARG(dtype == CS_F32 || dtype == CS_BF16, "stem_wgrad: bad dtype");
+    WgradParams p{};
+    p.x = x_pair; p.dy = dy; p.dw = dw_pair_slabs;
+    stem_wgrad_params(p, N, H, W, K, dtype);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool wide = K > 64;
+    if (dtype == CS_F32) return wide ? launch_wgrad<float, 128, 128, false>(p, st) : launch_wgrad<float, 64, 128, false>(p, st);
+    if (use_tr_read) return wide ? launch_wgrad<bf16_t, 128, 128, true>(p, st) : launch_wgrad<bf16_t, 64, 128, true>(p, st);
+    return wide ? launch_wgrad<bf16_t, 128, 128, false>(p, st) : launch_wgrad<bf16_t, 64, 128, false>(p, st);
+}
+
+extern "C" int cs_stem_unpair_slabs(const float* dw_pair_slabs, int nsplit, int K, float* dw_khwc, void* stream) {
+    CS_CHECK_ARG(dw_pair_slabs && dw_khwc && nsplit >= 1 && K > 0, "stem_unpair_slabs: bad arguments");
+    const int total = K * 392;
+    hipLaunchKernelGGL(stem_unpair_slabs_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dw_pair_slabs, nsplit,
+                       K, dw_khwc);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
 }

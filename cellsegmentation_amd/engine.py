@@ -277,13 +277,23 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 if (record is not None and not batch_stats and u.bn is not None and not u.grouped
                         and any(p_ is not None and p_.requires_grad for p_ in (conv.weight, conv.bias, u.bn.weight, u.bn.bias))):
                     record.append((ui, conv, u.bn, Cp, Kp, need_bwd))
+            # the stem runs on a pixel-paired image (kernels.stem_*): 28 instead of 49 K chunks
+            stem = STEM_PAIRED and K.is_stem_geom(geom) and not u.grouped and res is None and conv.in_channels <= 3
+            xp = K.stem_pair_input(x) if stem else None
+            wp = K.stem_pair_weights(st.w_khwc) if stem else None
             if not batch_stats:
-                y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped)
-                aux[ui] = SimpleNamespace(geom=geom, st=st, train=False)
+                if stem:
+                    y = K.stem_fwd(geom, xp, wp, None, st.shift, u.act)
+                else:
+                    y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped)
+                aux[ui] = SimpleNamespace(geom=geom, st=st, train=False, xp=xp)
             else:
                 bn = u.bn
                 stats = take_stats(Kp)
-                z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats, grouped=u.grouped)
+                if stem:
+                    z = K.stem_fwd(geom, xp, wp, None, st.shift, ACT_NONE, stats=stats)
+                else:
+                    z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats, grouped=u.grouped)
                 M = N * geom.P * geom.Q
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 mean, rstd = K.bn_finalize(stats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
@@ -291,7 +301,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
                     bumped.append(bn.num_batches_tracked)
                 y = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), res, u.act)
-                aux[ui] = SimpleNamespace(geom=geom, st=st, train=True, z=z if save else None, mean=mean, rstd=rstd)
+                aux[ui] = SimpleNamespace(geom=geom, st=st, train=True, z=z if save else None, mean=mean, rstd=rstd, xp=xp)
             t[u.dst] = y
         elif u.kind == "dw":
             x = t[u.src]
@@ -382,6 +392,7 @@ def _defers(u, a, need, ui):
             and not a.train and not u.grouped and u.bn is not None and u.conv.bias is None)
 
 
+STEM_PAIRED = os.environ.get("CELLSEG_STEM_PAIRED", "1") != "0"      # pixel-paired stem (0: the generic 7x7 path, for A/B runs)
 _grad_sink = None
 # batched weight gradients on a second HIP stream, concurrently with the dgrad chain: measured 2 % SLOWER on the ResNet-50 tile step
 # (6395 vs 6522 tiles/s: the groups complete late and then compete with the HBM-bound dgrads of the next stage), so opt-in only
@@ -478,7 +489,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         if side is None:
             return flush_on_current(items)
         for it in items:
-            for t_ in (it.x, it.dz, it.a.st.scale, it.a.st.rstd, getattr(it.gsum, "buf", it.gsum)):
+            for t_ in (it.x, it.dz, it.a.xp, it.a.st.scale, it.a.st.rstd, getattr(it.gsum, "buf", it.gsum)):
                 if t_ is not None:
                     t_.record_stream(side)           # allocated on the main stream, read by side-stream kernels
         side.wait_stream(main)
@@ -495,7 +506,10 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         dbs = [grad_buffer(it.u.bn.bias) for it in items]
         dots = [take((convs[0].out_channels,)) for _ in items]
         # (single layers take the same path: its finalize folds deferred column sums, the stand-alone one does not)
-        slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
+        if n == 1 and items[0].a.xp is not None:
+            slabs = K.stem_wgrad(geom, items[0].a.xp, items[0].dz, use_tr_read=use_tr_read).unsqueeze(0)     # [1, 1, K, 7, 7, 8]
+        else:
+            slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
         pending = sum(1 for it in items if isinstance(it.gsum, K.PartialColsum) and it.gsum._vec is None)
         gsums = K.fold_partial_batched([it.gsum for it in items], zeros=take((pending, geom.K)) if pending else None)
         K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
@@ -568,8 +582,11 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum = K.colsum(dz)
                     if not a.train and u.res is not None and grads.get(u.res) is g:
                         gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
-                raw = K.new_wgrad_buffer(geom, x.device, u.grouped)
-                K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
+                if a.xp is not None:
+                    raw = K.stem_wgrad(geom, a.xp, dz, use_tr_read=use_tr_read)
+                else:
+                    raw = K.new_wgrad_buffer(geom, x.device, u.grouped)
+                    K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
                 dw = grad_buffer(conv.weight)
                 dbias = grad_buffer(conv.bias) if want_b else None
                 dgamma = dbeta = None

@@ -240,6 +240,54 @@ def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_
     return y
 
 
+# ---------------------------------------------------------------- stem on a pixel-paired image (cs_stem_*)
+def is_stem_geom(geom):
+    """Conv2d(3 -> K, 7x7, stride 2, padding 3) on an NHWC8 image: the layer the paired path replaces."""
+    return geom.R == 7 and geom.S == 7 and geom.stride == 2 and geom.pad == 3 and geom.C == 8
+
+
+def stem_pair_input(x):
+    """x[N,H,W,8] (channels 3.. zero) -> [N,H,ceil(W/2),8]: two neighbouring pixels x 4 channels per 16-byte chunk."""
+    N, H, W, C = x.shape
+    if C != 8:
+        raise ValueError("stem_pair_input expects an NHWC image with 8 stored channels")
+    out = torch.empty((N, H, (W + 1) // 2, 8), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().cs_stem_pair_input(_p(x), _code(x.dtype), N, H, W, _p(out), _stream()), "stem_pair_input")
+    return out
+
+
+def stem_pair_weights(w_khwc):
+    """staged [K,7,7,8] -> paired [K,7,4,8]."""
+    K_ = w_khwc.shape[0]
+    out = torch.empty((K_, 7, 4, 8), dtype=w_khwc.dtype, device=w_khwc.device)
+    _lib.check(_lib.load().cs_stem_pair_weights(_p(w_khwc), _code(w_khwc.dtype), K_, _p(out), _stream()), "stem_pair_weights")
+    return out
+
+
+def stem_fwd(geom, x_pair, w_pair, scale=None, shift=None, act=CS_ACT_NONE, stats=None):
+    """cs_conv2d_fwd of the stem geometry `geom` (the 7x7 one: it names the launch for the timers) on paired operands."""
+    y = torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x_pair.dtype, device=x_pair.device)
+    lib = _lib.load()
+    ws = _stats_ws(geom.N * geom.P * geom.Q, geom.K, x_pair.device) if stats is not None else None
+    _lib.check(_timed("fwd", geom, x_pair.dtype, lambda: lib.cs_stem_fwd(
+        geom.N, geom.H, geom.W, geom.K, _code(x_pair.dtype), _p(x_pair), _p(w_pair), _p(scale), _p(shift), act, _p(y), _p(stats), _p(ws),
+        _stream())), "stem_fwd")
+    return y
+
+
+def stem_wgrad(geom, x_pair, dy, use_tr_read=True):
+    """Raw weight gradient of the stem in the ORDINARY slab layout [1, K, 7, 7, 8] (one slab: the paired split-K slabs are summed
+    while they are un-paired), ready for wgrad_finalize / wgrad_finalize_batched."""
+    lib = _lib.load()
+    nsplit = lib.cs_stem_wgrad_splits(geom.N, geom.H, geom.W, geom.K)
+    pair = torch.empty((nsplit, geom.K, 7, 4, 8), dtype=torch.float32, device=dy.device)
+    _lib.check(_timed("wgrad", geom, dy.dtype, lambda: lib.cs_stem_wgrad(
+        geom.N, geom.H, geom.W, geom.K, _code(dy.dtype), _p(x_pair), _p(dy), _p(pair), 1 if use_tr_read else 0, _stream())), "stem_wgrad")
+    raw = torch.empty((1, geom.K, 7, 7, 8), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.cs_stem_unpair_slabs(_p(pair), nsplit, geom.K, _p(raw), _stream()), "stem_unpair_slabs")
+    return raw
+
+
 class PartialColsum:
     """Column sums of a dgrad output still in per-workgroup partial rows (cs_conv2d_dgrad with colsum == NULL): the batched
     weight-gradient finalize folds them itself; vector() folds them now for any other consumer."""

@@ -283,6 +283,24 @@ int cs_segmented_topk(const float* probs, const int32_t* groups, const int32_t* 
                       const int64_t* seg_offsets, int n_groups, int max_run, long long T, int64_t* out_idx,
                       int64_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- stem on a pixel-paired image (Conv2d(3, 64, 7, stride 2, padding 3), model/resnet.py:111) ---------------------------
+ * With 3 channels padded to one 16-byte chunk per pixel the implicit GEMM walks 49 chunks of which 147/392 elements are real.
+ * Two neighbouring pixels x 4 channels per chunk make it a 7x4-tap convolution over x_pair[N][H][ceil(W/2)][8] (row stride 2,
+ * pair stride 1, pad (3, 2)): 28 chunks, 1.75x less MFMA work and DMA traffic, same kernels.
+ *   cs_stem_pair_input  : NHWC8 image (channels 3..7 zero) -> x_pair
+ *   cs_stem_pair_weights: staged w_khwc[K][7][7][8] (BN scale already folded) -> w_pair[K][7][4][8]
+ *   cs_stem_fwd         : as cs_conv2d_fwd (scale/shift/act/stats/workspace), y[N][P][Q][K], P = (H - 1) / 2 + 1
+ *   cs_stem_wgrad       : raw split-K slabs dw_pair[cs_stem_wgrad_splits][K][7][4][8] from x_pair and dy
+ *   cs_stem_unpair_slabs: those slabs summed into ONE ordinary raw slab dw_khwc[K][7][7][8] (input of cs_wgrad_finalize*) */
+int cs_stem_pair_input(const void* x_nhwc8, int dtype, int N, int H, int W, void* x_pair, void* stream);
+int cs_stem_pair_weights(const void* w_khwc, int dtype, int K, void* w_pair, void* stream);
+int cs_stem_fwd(int N, int H, int W, int K, int dtype, const void* x_pair, const void* w_pair, const float* scale, const float* shift,
+                int act, void* y, double* stats, void* workspace, void* stream);
+int cs_stem_wgrad_splits(int N, int H, int W, int K);
+int cs_stem_wgrad(int N, int H, int W, int K, int dtype, const void* x_pair, const void* dy, float* dw_pair_slabs, int use_tr_read,
+                  void* stream);
+int cs_stem_unpair_slabs(const float* dw_pair_slabs, int nsplit, int K, float* dw_khwc, void* stream);
+
 /* ---- the steps either side of the top-k -----------------------------------------------------------
  * cs_segmented_order: order = np.lexsort((probs, groups)) alone (train_seg.py:239, evaluate.py:13); order[T] int64.
  * cs_threshold_select: order[[p > threshold for p in probs[order]]] (train_seg.py:243-245), i.e. `rank`'s tile list;

@@ -183,3 +183,43 @@ def test_grouped_conv_slab_dense(cfg, dtype, dev, igemm_path):
     assert _relerr(_from_nhwc(yd, C), y.detach()) < TOL[dtype]
     assert _relerr(_from_nhwc(dxd, C), x.grad) < TOL[dtype]
     assert _relerr(dw.cpu(), w.grad) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(37, 41), (32, 32), (75, 64)])
+def test_paired_stem_equals_the_generic_7x7_path(dev, dtype, hw):
+    """cs_stem_* (two pixels x 4 channels per chunk, 7x4 taps) against cs_conv2d_fwd / _wgrad on the same NHWC8 image: odd and
+    even widths, the last pixel of an odd row paired with a zero."""
+    from cellsegmentation_amd import kernels as K
+    H, W = hw
+    N, Kc = 3, 64
+    g = K.make_geom(N, H, W, 8, Kc, 7, 7, 2, 3)
+    assert K.is_stem_geom(g)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.zeros((N, H, W, 8))
+    x[..., :3] = torch.randn((N, H, W, 3), generator=gen)
+    x = x.to(dev).to(dtype)
+    w = (torch.randn((Kc, 3, 7, 7), generator=gen) * 0.1).to(dev)
+    shift = torch.randn((Kc,), generator=gen).to(dev)
+    wk, _ = K.weight_prep(w, None, dtype, 8, Kc, True, False)
+    y_ref = K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_RELU)
+    xp, wp = K.stem_pair_input(x), K.stem_pair_weights(wk)
+    assert tuple(xp.shape) == (N, H, (W + 1) // 2, 8) and tuple(wp.shape) == (Kc, 7, 4, 8)
+    y = K.stem_fwd(g, xp, wp, None, shift, K.CS_ACT_RELU)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((y.float() - y_ref.float()).abs().max()) <= tol * max(1.0, float(y_ref.float().abs().max()))
+    # batch statistics through the same entry point
+    st_ref, st = K.new_stats(Kc, dev), K.new_stats(Kc, dev)
+    K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_NONE, stats=st_ref)
+    K.stem_fwd(g, xp, wp, None, shift, K.CS_ACT_NONE, stats=st)
+    assert torch.allclose(st, st_ref, rtol=1e-3 if dtype == torch.bfloat16 else 1e-6, atol=1e-3)
+    # weight gradient
+    dy = torch.randn((N, g.P, g.Q, Kc), generator=gen).to(dev).to(dtype)
+    raw_ref = K.new_wgrad_buffer(g, dev)
+    K.conv_wgrad(g, x, dy, raw_ref)
+    ref = raw_ref.sum(0)
+    raw = K.stem_wgrad(g, xp, dy)
+    assert tuple(raw.shape) == (1, Kc, 7, 7, 8)
+    scale = float(ref.abs().max())
+    assert float((raw[0] - ref).abs().max()) <= (1e-4 if dtype == torch.float32 else 1e-3) * scale
+    assert float(raw[0][..., 3:].abs().max()) == 0.0
