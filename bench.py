@@ -87,7 +87,7 @@ def kernel_name(kind, g, dtype):
         M, nout, suffix = g["N"] * g["H"] * g["W"], g["C"], ""
         if g["stride"] > 1:                        # one stride-1 launch per destination parity class
             M = M // (g["stride"] ** 2)
-            suffix = f" x{g['stride'] ** 2} parity classes"
+            suffix = f" x{g['stride'] ** 2} parity classes"       # one launch covering the stride^2 destination parity classes
     bm, bn = K.igemm_tile(M, nout)
     mode = 0 if (g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0) else 1
     # epilogue-operand prefetch variant: bf16, more than one 64-element K-step, a residual/add/mask operand, identity destination

@@ -51,6 +51,10 @@ struct IgemmParams {
     int cslab;
     long long M;      // N*DH*DW
     long long src_pixels;   // N*SH*SW
+    // strided data gradient: up to 4 destination parity classes in ONE launch; workgroup -> class by block0, the class's
+    // geometry replaces the fields of the same name (LDS-DMA kernel only)
+    int ncls;
+    struct ClassOv { int DH, DW, off0, off0x, R, S, wk0y, wk0x, Qtot, dst_oy, dst_ox, block0, row0; long long M; } cls[4];
     int Qtot;         // R*S*SCc (taps walked by this launch)
     int wrow_chunks;  // chunks per weight row (full filter)
     int SCc;          // SC / chunk
@@ -484,7 +488,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 //    soffset (zero VALU per DMA); MODE-1 pixels add the tap offset and test one bit of a 32-bit validity mask (4 VALU per DMA).
 //    The lane-by-lane walk it replaces cost ~8 VALU + 6 SALU per MFMA (PMC), more issue slots than the MFMAs themselves.
 template <typename T, int BM, int BN, int MODE, bool PF = false, bool UNI = false>
-__global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams p, unsigned src_bytes, unsigned wgt_bytes) {
+__global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams p_in, unsigned src_bytes, unsigned wgt_bytes) {
+    IgemmParams p = p_in;
+    unsigned bid = blockIdx.x;
+    int slab_row0 = 0;
+    if (p_in.ncls) {
+        // wave-uniform selection with static indices only (a runtime index into the by-value argument would go through scratch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < p_in.ncls && blockIdx.x >= (unsigned)p_in.cls[i].block0) {
+                p.DH = p_in.cls[i].DH; p.DW = p_in.cls[i].DW; p.off0 = p_in.cls[i].off0; p.off0x = p_in.cls[i].off0x;
+                p.R = p_in.cls[i].R; p.S = p_in.cls[i].S; p.wk0y = p_in.cls[i].wk0y; p.wk0x = p_in.cls[i].wk0x;
+                p.Qtot = p_in.cls[i].Qtot; p.dst_oy = p_in.cls[i].dst_oy; p.dst_ox = p_in.cls[i].dst_ox; p.M = p_in.cls[i].M;
+                bid = blockIdx.x - (unsigned)p_in.cls[i].block0;
+                slab_row0 = p_in.cls[i].row0;
+            }
+    }
     constexpr int ES = (int)sizeof(T);
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AI = BM / 32, BI = BN / 32;
@@ -503,8 +522,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
     // one M tile run back-to-back on ONE XCD: the second N tile finds the source rows in that XCD's L2 and the two
     // half-row output writes meet there before they go to HBM.
     const int n_ntiles = (p.NOUT + BN - 1) / BN;
-    const unsigned slot = blockIdx.x >> 3;
-    const long long mtile = (long long)(slot / n_ntiles) * 8 + (blockIdx.x & 7);
+    const unsigned slot = bid >> 3;
+    const long long mtile = (long long)(slot / n_ntiles) * 8 + (bid & 7);
     const long long m0 = mtile * BM;
     const int n0 = (int)(slot % n_ntiles) * BN;
     if (m0 >= p.M) return;     // grid is padded to 8 M tiles per round
@@ -721,8 +740,9 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void igemm_dma_kernel(IgemmParams 
                 for (int j = 0; j < TN; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // a launch with no K-step still has its (all-zero) first stage in flight
     __syncthreads();
-    igemm_epilogue<T, BM, BN, PF>(p, acc, smem_raw, m0, n0, mtile, &er);
+    igemm_epilogue<T, BM, BN, PF>(p, acc, smem_raw, m0, n0, slab_row0 + mtile, &er);
 }
 
 
@@ -854,6 +874,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
 int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
                             // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
+const bool g_merge_classes = [] { const char* e = getenv("CELLSEG_NO_MERGE"); return !(e && atoi(e)); }();   // A/B experiments only
 const bool g_uni_walk = [] { const char* e = getenv("CELLSEG_NO_UNI"); return !(e && atoi(e)); }();   // A/B experiments only
 const bool g_epi_prefetch = [] { const char* e = getenv("CELLSEG_NO_EPI_PREFETCH"); return !(e && atoi(e)); }();   // A/B experiments only
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
@@ -875,6 +896,31 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     if (lds < red_bytes) lds = red_bytes;
     const unsigned n_mt = (unsigned)((p.M + BM - 1) / BM), n_nt = (unsigned)((p.NOUT + BN - 1) / BN);
     dim3 grid(((n_mt + 7) / 8) * 8 * n_nt, 1, 1);             // see the tile-order note in the kernels
+    if (p.ncls) {
+        // all parity classes of a strided data gradient in one launch (caller checked: DMA-able, tap-walking mode for every class)
+        IgemmParams q = p;
+        unsigned b0 = 0;
+        int r0 = 0, max_nk = 0;
+        for (int i = 0; i < q.ncls; ++i) {
+            const unsigned mt = (unsigned)((q.cls[i].M + BM - 1) / BM);
+            q.cls[i].block0 = (int)b0;
+            q.cls[i].row0 = r0;
+            b0 += ((mt + 7) / 8) * 8 * n_nt;
+            r0 += (int)mt;
+            const int nk_c = (q.cls[i].Qtot + 7) / 8;
+            if (nk_c > max_nk) max_nk = nk_c;
+        }
+        size_t clds = (max_nk <= 1 ? 1 : 2) * one_stage;
+        if (clds < epi_bytes) clds = epi_bytes;
+        if (clds < red_bytes) clds = red_bytes;
+        const bool uni = g_uni_walk && q.SCc % 8 == 0;       // every class has R*S <= 4 taps here
+        const unsigned long long sb = (unsigned long long)q.src_pixels * q.SC * sizeof(T);
+        const unsigned long long wb = (unsigned long long)q.NOUT * q.wrow_chunks * 16ull;
+        if (uni) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, true>), dim3(b0), dim3(256), clds, st, q, (unsigned)sb, (unsigned)wb);
+        else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, false>), dim3(b0), dim3(256), clds, st, q, (unsigned)sb, (unsigned)wb);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     const unsigned long long src_bytes = (unsigned long long)p.src_pixels * p.SC * sizeof(T);
     const unsigned long long wgt_bytes = (unsigned long long)p.NOUT * p.wrow_chunks * 16ull;
     const bool dma = g_igemm_path == 0 && src_bytes < 0x80000000ull && wgt_bytes < 0x80000000ull;
@@ -969,7 +1015,11 @@ int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream
     }
     if (rc != CS_OK || !p.slab || (!colsum && !stats)) return rc;      // no colsum/stats target: the partial rows are the result
     const int bm = tile / 1000;
-    const int rows = (int)((p.M + bm - 1) / bm);
+    int rows = (int)((p.M + bm - 1) / bm);
+    if (p.ncls) {
+        rows = 0;
+        for (int i = 0; i < p.ncls; ++i) rows += (int)((p.cls[i].M + bm - 1) / bm);
+    }
     const int ncols = stats ? 2 * p.NOUT : p.NOUT;
     int chunks = rows / 64;
     if (chunks < 1) chunks = 1;
@@ -1147,6 +1197,43 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     // kh == (py+pad) mod s (same for kw), for which the source row is a + (py+pad-kh)/s.  Classes without
     // taps still run (zero K-steps) so that `add`/`mask` are applied and dx is fully written.
     const int sd = g->stride;
+    {
+        // stride 2: the (up to) four classes go out as ONE launch when the LDS-DMA kernel can take them -- four quarter-size
+        // launches (one of them with 4 taps, one with 1) never filled the chip and each paid its own ramp and column-sum fold
+        const unsigned long long esz = dtype == CS_F32 ? 4 : 2;
+        const unsigned long long sbytes = (unsigned long long)p.src_pixels * p.SC * esz, wbytes = (unsigned long long)p.NOUT * p.wrow_chunks * 16ull;
+        IgemmParams q = p;
+        int n = 0;
+        bool ok = sd == 2 && g_igemm_path == 0 && sbytes < 0x80000000ull && wbytes < 0x80000000ull && !slab && g_merge_classes;
+        long long max_m = 0;
+        for (int py = 0; ok && py < sd; ++py)
+            for (int px = 0; px < sd; ++px) {
+                const int kh0 = (py + g->pad) % sd, kw0 = (px + g->pad) % sd;
+                const int nj = kh0 < g->R ? (g->R - kh0 + sd - 1) / sd : 0;
+                const int ni = kw0 < g->S ? (g->S - kw0 + sd - 1) / sd : 0;
+                const int dh = (g->H - py + sd - 1) / sd, dw = (g->W - px + sd - 1) / sd;
+                if (dh <= 0 || dw <= 0) continue;
+                IgemmParams::ClassOv& c = q.cls[n++];
+                c.DH = dh; c.DW = dw;
+                c.off0 = (py + g->pad - kh0) / sd; c.off0x = (px + g->pad - kw0) / sd;
+                c.R = nj; c.S = ni;
+                if (nj == 0 || ni == 0) { c.R = 0; c.S = 1; }
+                c.wk0y = kh0; c.wk0x = kw0;
+                c.Qtot = c.R * c.S * p.SCc;
+                c.dst_oy = py; c.dst_ox = px;
+                c.M = (long long)g->N * dh * dw;
+                c.block0 = 0; c.row0 = 0;
+                if (c.M > max_m) max_m = c.M;
+            }
+        if (ok && n > 0) {
+            q.ncls = n;
+            q.div = 1; q.mul = 1; q.mulx = 1; q.sgn = -1; q.wkstep = sd; q.dst_step = sd;
+            q.R = 1; q.S = 2;                       // any tap-walking shape: the per-class values replace them in the kernel
+            q.Qtot = q.cls[0].Qtot;
+            q.M = max_m;                            // tile choice
+            return dtype == CS_F32 ? dispatch_igemm<float>(q, colsum, nullptr, st) : dispatch_igemm<bf16_t>(q, colsum, nullptr, st);
+        }
+    }
     for (int py = 0; py < sd; ++py) {
         for (int px = 0; px < sd; ++px) {
             IgemmParams c = p;
@@ -1830,8 +1917,18 @@ __global__ void stem_unpair_slabs_kernel(const float* __restrict__ slabs, int ns
     float v = 0.f;
     if (c < 3) {
         const int kwp = (kw + 1) >> 1, e = 4 * ((kw + 1) & 1) + c;
-        const long long src = ((long long)(k * 7 + kh) * 4 + kwp) * 8 + e;
-        for (int s = 0; s < nsplit; ++s) v += slabs[(long long)s * K * 224 + src];
+        const float* src = slabs + ((long long)(k * 7 + kh) * 4 + kwp) * 8 + e;
+        const long long stride = (long long)K * 224;
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.f;
+        int s = 0;
+        for (; s + 8 <= nsplit; s += 8) {          // the stem is split ~256 ways: keep 8 loads in flight per thread
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += src[(s + u) * stride];
+        }
+        for (; s < nsplit; ++s) a[0] += src[s * stride];
+        v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     out[idx] = v;
 }
