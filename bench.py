@@ -93,7 +93,13 @@ def kernel_name(kind, g, dtype):
     # epilogue-operand prefetch variant: bf16, more than one 64-element K-step, a residual/add/mask operand, identity destination
     contracted = (g["C"] if kind == "fwd" else g["K"]) * g["R"] * g["S"]
     pf = dt == "bf16" and contracted > 64 and g["extra"] > 0 and not suffix
-    return f"igemm_dma_kernel<{dt},{bm},{bn},{mode},{'true' if pf else 'false'}>{suffix}"
+    # scalar K walk (UNI): every 1x1/s1 launch; tap-walking launches whose tap is wave-uniform (contracted channels % 64 == 0 in
+    # bf16, % 32 in fp32) with at most 32 taps -- the paired stem (8 channels per tap) and 7x7 kernels are not
+    cc = g["C"] if kind == "fwd" else g["K"]
+    per_step = 64 if dt == "bf16" else 32
+    taps = g["R"] * g["S"] if not suffix else 4
+    uni = mode == 0 or (cc % per_step == 0 and taps <= 32 and not (g["R"] == 7 and g["C"] == 8))
+    return f"igemm_dma_kernel<{dt},{bm},{bn},{mode},{'true' if pf else 'false'},{'true' if uni else 'false'}>{suffix}"
 
 
 def roofline_from(records, steps, dtype):
