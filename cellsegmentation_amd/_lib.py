@@ -76,6 +76,9 @@ _SIGNATURES = {
     "cs_bn_bwd_reduce": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_longlong, c_int, _P, _P, _P]),
     "cs_bn_bwd_apply": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_longlong, c_int, _P, _P, _P, _P]),
     "cs_dwconv_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "cs_dwconv_fwd_stats_workspace": (c_size_t, [POINTER(CsConvGeom)]),
+    "cs_dwconv_fwd_stats": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, POINTER(c_int), _P]),
+    "cs_bn_partial_fold": (c_int, [_P, c_int, c_int, _P, _P]),
     "cs_dwconv_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P]),
     "cs_dwconv_wgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P]),
     "cs_se_scale": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P]),

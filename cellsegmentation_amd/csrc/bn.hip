@@ -224,24 +224,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-// out[j] += sum_b partial[b][j] for the 2*C columns of the per-workgroup partial sums; gridDim.y row chunks -> <= 8 atomics per address
+// out[j] += sum_b partial[b][j] for the 2*C columns of the per-workgroup partial sums.  Workgroup = 64 columns x 4 row lanes,
+// gridDim.y row chunks -> <= 32 fp64 atomics per address (a column-per-thread walk over ~1000 rows was latency-bound: 38 us)
 __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __restrict__ partial, int blocks, int cols, double* __restrict__ out) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     const int per = (blocks + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per;
     int b1 = b0 + per;
     if (b1 > blocks) b1 = blocks;
-    double acc = 0.0;
-    for (int b = b0; b < b1; ++b) acc += partial[(long long)b * cols + j];
-    if (b0 < blocks) atomicAdd(out + j, acc);
+    double a0 = 0.0, a1 = 0.0;
+    if (j < cols) {
+        int b = b0 + rl;
+        for (; b + 4 < b1; b += 8) { a0 += partial[(long long)b * cols + j]; a1 += partial[(long long)(b + 4) * cols + j]; }
+        for (; b < b1; b += 4) a0 += partial[(long long)b * cols + j];
+    }
+    __shared__ double part[4][64];
+    part[rl][threadIdx.x & 63] = a0 + a1;
+    __syncthreads();
+    if (rl == 0 && j < cols && b0 < blocks) atomicAdd(out + j, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
 inline int fold_partial(const double* partial, int blocks, int C, double* out, hipStream_t st) {
-    int chunks = blocks / 128;
+    int chunks = blocks / 16;
     if (chunks < 1) chunks = 1;
-    if (chunks > 8) chunks = 8;
-    hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((2 * C + 255) / 256, chunks), dim3(256), 0, st, partial, blocks, 2 * C, out);
+    if (chunks > 32) chunks = 32;
+    hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((2 * C + 63) / 64, chunks), dim3(256), 0, st, partial, blocks, 2 * C, out);
     return 0;
 }
 
@@ -264,6 +272,13 @@ inline int grid_ew(long long total) {
     if (dtype == CS_F32) { CALL_F32; }                       \
     else if (dtype == CS_BF16) { CALL_BF16; }                \
     else { cs_set_error_(NAME ": bad dtype"); return CS_ERR_INVALID_ARG; }
+
+extern "C" int cs_bn_partial_fold(const double* partial, int rows, int C, double* stats, void* stream) {
+    CS_CHECK_ARG(partial && stats && rows > 0 && C > 0, "bn_partial_fold: bad arguments");
+    fold_partial(partial, rows, C, stats, reinterpret_cast<hipStream_t>(stream));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
 
 extern "C" size_t cs_bn_partial_workspace(long long M, int C) {
     if (M <= 0 || C <= 0) return 0;

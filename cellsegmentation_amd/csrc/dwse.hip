@@ -260,6 +260,63 @@ __global__ __launch_bounds__(256) void rowscale_add_kernel(const T* __restrict__
     }
 }
 
+// Depthwise forward that also leaves the per-channel sum / sum of squares of the STORED output (train-mode BN statistics) as one
+// partial row per workgroup: partial[(2*b + {0,1}) * C + c] in fp64 -- folded by cs_bn_partial_fold.  Saves the separate
+// cs_bn_stats pass over z (26 launches of ~100 us per EfficientNet-B3 step).  The grid is a multiple of CG / gcd(CG, 256)
+// workgroups, so a thread keeps its 8 channels for its whole grid-stride walk and accumulates in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                           double* __restrict__ partial, int N, int H, int W, int C, int R, int stride,
+                                                           int pad, int P, int Q) {
+    extern __shared__ float lsum[];          // [2][C]
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+    const int CG = C / 8;
+    const long long total = (long long)N * P * Q * CG;
+    const long long first = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(first % CG);        // constant along the walk: gridDim.x * 256 is a multiple of CG
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (long long idx = first; idx < total; idx += (long long)gridDim.x * 256) {
+        long long t = idx / CG;
+        const int ox = (int)(t % Q); t /= Q;
+        const int oy = (int)(t % P);
+        const long long n = t / P;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int kh = 0; kh < R; ++kh) {
+            const int iy = oy * stride - pad + kh;
+            if (iy < 0 || iy >= H) continue;
+            for (int kw = 0; kw < R; ++kw) {
+                const int ix = ox * stride - pad + kw;
+                if (ix < 0 || ix >= W) continue;
+                float v[8], wp[8];
+                load8<T>(x + ((n * H + iy) * (long long)W + ix) * C + cg * 8, v);
+                load8p(w + (kh * R + kw) * C + cg * 8, 0.f, wp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e] * wp[e];
+            }
+        }
+        store8<T>(y + ((n * P + oy) * (long long)Q + ox) * C + cg * 8, acc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float r = to_f32<T>(from_f32<T>(acc[e]));       // statistics of the stored (rounded) value
+            s1[e] += r; s2[e] += r * r;
+        }
+    }
+    if (first < total) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(&lsum[cg * 8 + e], s1[e]);
+            atomicAdd(&lsum[C + cg * 8 + e], s2[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) partial[(long long)blockIdx.x * 2 * C + i] = (double)lsum[i];
+}
+
 inline int grid_ew(long long total) {
     long long b = (total + 255) / 256;
     if (b > 16384) b = 16384;
@@ -294,6 +351,42 @@ extern "C" int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, cons
                                    g->N, g->H, g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q),
                 hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w_hwc, scale, shift, act,
                                    (bf16_t*)y, g->N, g->H, g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+static int dw_stats_grid(const CsConvGeom* g) {
+    const int CG = g->C / 8;
+    int a = CG, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }           // gcd(CG, 256)
+    const int m = CG / a;                                      // workgroup-count granule
+    long long want = ((long long)g->N * g->P * g->Q * CG + 255) / 256;
+    if (want > 1024) want = 1024;
+    long long grid = (want + m - 1) / m * m;
+    if (grid < m) grid = m;
+    return (int)grid;
+}
+
+extern "C" size_t cs_dwconv_fwd_stats_workspace(const CsConvGeom* g) {
+    if (!g || g->C <= 0 || g->C % 8) return 0;
+    return (size_t)dw_stats_grid(g) * 2 * (size_t)g->C * sizeof(double);
+}
+
+extern "C" int cs_dwconv_fwd_stats(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, void* y, double* partial,
+                                   int* partial_rows, void* stream) {
+    int rc = check_dw(g, "dwconv_fwd_stats: bad geometry (square filter, K == C, C % 8 == 0 required)");
+    if (rc) return rc;
+    CS_CHECK_ARG(x && w_hwc && y && partial && partial_rows, "dwconv_fwd_stats: NULL argument");
+    CS_CHECK_ARG((size_t)2 * g->C * sizeof(float) <= 65536, "dwconv_fwd_stats: too many channels for the LDS fold");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = dw_stats_grid(g);
+    const size_t lds = (size_t)2 * g->C * sizeof(float);
+    *partial_rows = grid;
+    CS_T_SWITCH(dtype, "dwconv_fwd_stats",
+                hipLaunchKernelGGL(dw_fwd_stats_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)x, w_hwc, (float*)y, partial, g->N,
+                                   g->H, g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q),
+                hipLaunchKernelGGL(dw_fwd_stats_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, (const bf16_t*)x, w_hwc, (bf16_t*)y, partial,
+                                   g->N, g->H, g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q));
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -311,10 +311,10 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             geom = K.make_geom(N, H, W, C, C, R, R, conv.stride[0], conv.padding[0])
             w_hwc = conv.weight.detach()[:, 0].permute(1, 2, 0).contiguous()
             if _bn_uses_batch_stats(bn, bn_train):
-                z = K.dwconv_fwd(geom, x, w_hwc)
+                z, zstats = K.dwconv_fwd_stats(geom, x, w_hwc)
                 M = N * geom.P * geom.Q
                 momentum = bn.momentum if bn.momentum is not None else 0.1
-                mean, rstd = K.bn_finalize(K.bn_stats(z), M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
+                mean, rstd = K.bn_finalize(zstats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
                                            bn.running_var if bn.track_running_stats else None)
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
                     bumped.append(bn.num_batches_tracked)

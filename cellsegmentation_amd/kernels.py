@@ -539,6 +539,19 @@ def dwconv_fwd(geom, x, w_hwc, scale=None, shift=None, act=CS_ACT_NONE):
     return y
 
 
+def dwconv_fwd_stats(geom, x, w_hwc):
+    """Raw depthwise output z and its train-mode BN statistics (fp64 [2, C]) from one pass."""
+    lib = _lib.load()
+    y = torch.empty((geom.N, geom.P, geom.Q, geom.C), dtype=x.dtype, device=x.device)
+    ws = torch.empty((lib.cs_dwconv_fwd_stats_workspace(ctypes.byref(geom)) // 8,), dtype=torch.float64, device=x.device)
+    rows = ctypes.c_int(0)
+    _lib.check(lib.cs_dwconv_fwd_stats(ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_hwc), _p(y), _p(ws), ctypes.byref(rows), _stream()),
+               "dwconv_fwd_stats")
+    stats = new_stats(geom.C, x.device)
+    _lib.check(lib.cs_bn_partial_fold(_p(ws), rows.value, geom.C, _p(stats), _stream()), "bn_partial_fold")
+    return y, stats
+
+
 def dwconv_dgrad(geom, dy, w_hwc):
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     _lib.check(_lib.load().cs_dwconv_dgrad(ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_hwc), _p(dx), _stream()), "dwconv_dgrad")

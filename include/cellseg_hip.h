@@ -224,6 +224,13 @@ int cs_split_channels(const void* whole, int dtype, void* a, void* b, long long 
  * scale/shift (eval BN) and activation. */
 int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, const float* scale, const float* shift,
                   int act, void* y, void* stream);
+/* Depthwise forward for train-mode BN: y = raw conv output, and the per-channel sum / sum of squares of the stored y as
+ * *partial_rows per-workgroup rows partial[r][2][C] (fp64, cs_dwconv_fwd_stats_workspace(g) bytes); cs_bn_partial_fold adds the
+ * rows into stats[2][C] (zeroed by the caller) -- together they replace cs_dwconv_fwd + cs_bn_stats (one pass over y less). */
+size_t cs_dwconv_fwd_stats_workspace(const CsConvGeom* g);
+int cs_dwconv_fwd_stats(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, void* y, double* partial,
+                        int* partial_rows, void* stream);
+int cs_bn_partial_fold(const double* partial, int rows, int C, double* stats, void* stream);
 int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, const float* w_hwc, void* dx, void* stream);
 /* dw_hwc[R][S][C] fp32 += ... (zeroed by the caller) */
 int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, void* stream);
