@@ -238,8 +238,17 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_kernel(const float* __re
         const int j = c * RS + rs;
         const long long src = Cg_slab ? ((long long)k * RS + rs) * 64 + ((k % 64) / Cg_slab) * Cg_slab + c
                                       : ((long long)k * RS + rs) * Cp + c;
-        float raw = 0.f;
-        for (int z = 0; z < nsplit; ++z) raw += dw_khwc[z * slab_stride + src];
+        // small layers are split many ways (up to M/64 slices): keep 8 partial loads in flight instead of one
+        float a8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] = 0.f;
+        int z = 0;
+        for (; z + 8 <= nsplit; z += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += dw_khwc[(z + u) * slab_stride + src];
+        }
+        for (; z < nsplit; ++z) a8[0] += dw_khwc[z * slab_stride + src];
+        const float raw = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         const long long o = (long long)k * per + j;
         if (dot) contrib = w[o] * raw;
         const float val = (scale ? scale[k] : 1.f) * raw;
