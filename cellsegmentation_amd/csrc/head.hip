@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     if (idx >= (long long)N * K) return;
     const int n = (int)(idx / K), k = (int)(idx % K);
     float acc = 0.f, accb = 0.f;
+#pragma unroll 8
     for (int m = 0; m < M; ++m) {
         const float g = lin_act_grad(dy[(long long)m * N + n], act ? y[(long long)m * N + n] : 0.f, act);
         acc += g * x[(long long)m * K + k];
