@@ -1,0 +1,48 @@
+"""One training step as a HIP graph.
+
+The BN-train paths (image-wise counter, EfficientNet) issue ~1000 small launches per step from Python and are host-bound:
+4 ms of GPU work in a 7-10 ms step for the ResNet-18 counter at batch 8.  Every kernel of this library is enqueued on torch's
+current stream with caller-owned buffers and no host synchronisation, so a whole step -- forward, loss, the HIP backward,
+``optimizer.step()`` -- captures into one graph (`torch.cuda.CUDAGraph`, i.e. hipGraph on ROCm) and replays in a single launch:
+3.4 ms per step for that configuration.
+
+Constraints (torch's graph-capture rules): fixed input shapes (use the eager step for a ragged last batch), no `.item()` /
+`.cpu()` inside the step, an optimizer that supports capture (`torch.optim.Adam(..., capturable=True)`, SGD).  Parameters, BN
+running statistics and optimizer state are updated in place by the replay exactly as by the eager step.
+"""
+import torch
+
+
+class GraphedStep:
+    """``step = GraphedStep(step_fn, (x, y, ...))`` then ``loss = step(x, y, ...)`` per batch.
+
+    step_fn(*tensors) runs ONE full training step on its arguments and returns a tensor (e.g. the loss) or a tuple of tensors.
+    Construction runs `warmup` REAL steps on the example batch on a side stream (allocator warm-up, lazily built staging tables:
+    they do update the model), then captures one more into the graph without executing it.  Each call copies the new batch into
+    the captured input buffers and replays; the returned tensors are the captured outputs (overwritten by the next call)."""
+
+    def __init__(self, step_fn, example_inputs, warmup=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs a GPU")
+        self.static_inputs = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn(*self.static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = step_fn(*self.static_inputs)
+
+    def __call__(self, *inputs):
+        if len(inputs) != len(self.static_inputs):
+            raise ValueError("GraphedStep: expected %d inputs" % len(self.static_inputs))
+        for dst, src in zip(self.static_inputs, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError("GraphedStep: input shape/dtype differs from the captured one; run the eager step for this batch")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.outputs

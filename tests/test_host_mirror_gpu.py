@@ -177,3 +177,51 @@ def test_staged_weights_follow_the_optimizer(dev, fused):
         expect = fresh(x)
     assert float((after - before).abs().max()) > 1e-3          # the update is visible at all
     assert torch.equal(after, expect)
+
+
+def test_graphed_step_equals_eager_steps(dev):
+    """A training step captured into a HIP graph (graphed.GraphedStep) leaves the same parameters, BN running statistics and
+    loss as the same number of eager steps: image-mode ResNet-18 with batch-statistics BN, Adam."""
+    from cellsegmentation_amd import functional as HF
+    from cellsegmentation_amd.graphed import GraphedStep
+
+    def build():
+        m = _model("resnet18", dev)
+        m.setmode("image")
+        m.train()
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+        return m, opt
+
+    x = synth.normalise(synth.ihc_tiles(4, 64, 21)).to(dev)
+    cls = torch.tensor([0, 2, 1, 3], device=dev)
+    cnt = torch.tensor([0.0, 7.0, 2.0, 12.0], device=dev)
+
+    def make_step(m, opt):
+        def step(xb, cb, nb):
+            opt.zero_grad(set_to_none=True)
+            oc, orr = m(xb)
+            loss = HF.cross_entropy(oc, cb) + HF.mse_loss(orr.squeeze(1), nb)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+
+    m1, o1 = build()
+    eager = make_step(m1, o1)
+    for _ in range(2 + 3):                       # GraphedStep: 2 warm-up steps + 3 replays
+        l1 = eager(x, cls, cnt)
+    m2, o2 = build()
+    graphed = GraphedStep(make_step(m2, o2), (x, cls, cnt), warmup=2)
+    for _ in range(3):
+        (l2) = graphed(x, cls, cnt)
+    torch.cuda.synchronize()
+    assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l1)))
+    worst = 0.0
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if a.is_floating_point():
+            worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+        else:
+            assert torch.equal(a, b), k           # num_batches_tracked
+    assert worst < 1e-4, worst                    # fp32 atomics in a few reductions: summation order only
+    with pytest.raises(ValueError):
+        graphed(x[:2], cls[:2], cnt[:2])

@@ -58,6 +58,21 @@ if "c1" in which:
         (HF.cross_entropy(oc, cls) + HF.mse_loss(orr.squeeze(), counts.float())).backward()
         opt.step()
     run("c1 resnet18 image counter B=8 bf16 (fwd+bwd+Adam, BN train)", s1, 8, "images/s")
+    # the same step replayed as one HIP graph (cellsegmentation_amd.graphed): the eager step is host-bound (~1000 launches)
+    from cellsegmentation_amd.graphed import GraphedStep
+    m = fill(R.MILresnet18()); m.setmode("image"); m.train()
+    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=8e-5, weight_decay=1e-4, capturable=True)
+
+    def s1g_body(xb, cb, nb):
+        optg.zero_grad(set_to_none=True)
+        oc, orr = m(xb)
+        loss = HF.cross_entropy(oc, cb) + HF.mse_loss(orr.squeeze(), nb)
+        loss.backward()
+        optg.step()
+        return loss.detach()
+    gstep = GraphedStep(s1g_body, (x, cls, counts.float()))
+    cf = counts.float()
+    run("c1g same step as one HIP graph (GraphedStep)", lambda: gstep(x, cls, cf), 8, "images/s")
 if "c2f" in which:
     m = fill(R.MILresnet50()); m.setmode("tile"); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
