@@ -165,11 +165,11 @@ def per_layer_table(records, steps, dtype):
         key = (kind, g["R"], g["stride"], g["C"], g["K"], g["H"], g["extra"], g.get("batch", 1))
         e = rows.setdefault(key, [0.0, 0, conv_flops(g), conv_bytes(kind, g, es), kernel_name(kind, g, dt)])
         e[0] += ms; e[1] += 1
-    out = [f"{'kind':6s} {'RxR/s':6s} {'C':>5s} {'K':>5s} {'H':>4s} {'ex':>2s} {'b':>2s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'GB/s':>7s} {'TF/s':>7s}  kernel"]
+    out = [f"{'kind':6s} {'RxR/s':6s} {'C':>5s} {'K':>5s} {'H':>4s} {'ex':>4s} {'b':>2s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'GB/s':>7s} {'TF/s':>7s}  kernel"]
     for key, (ms, n, fl, by, name) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
         kind, R, st, C, Kc, H, ex, b = key
         avg = ms / n
-        out.append(f"{kind:6s} {R}x{R}/{st:<2d} {C:5d} {Kc:5d} {H:4d} {ex:2d} {b:2d} {n / steps:6.1f} {avg * 1e3:8.1f} {ms / steps:8.3f} "
+        out.append(f"{kind:6s} {R}x{R}/{st:<2d} {C:5d} {Kc:5d} {H:4d} {ex:4.2f} {b:2d} {n / steps:6.1f} {avg * 1e3:8.1f} {ms / steps:8.3f} "
                    f"{by / (avg * 1e-3) / 1e9:7.0f} {fl / (avg * 1e-3) / 1e12:7.1f}  {name}")
     return "\n".join(out)
 

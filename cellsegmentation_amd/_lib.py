@@ -45,6 +45,8 @@ _SIGNATURES = {
     "cs_igemm_tile": (c_int, [c_longlong, c_int]),
     "cs_set_igemm_path": (c_int, [c_int]),
     "cs_conv2d_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cs_conv2d_fwd_bits": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "cs_conv2d_dgrad_bits": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cs_conv2d_wgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, _P]),
     "cs_wgrad_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "cs_conv2d_wgrad_splits": (c_int, [POINTER(CsConvGeom), c_int]),

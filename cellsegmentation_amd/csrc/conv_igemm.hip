@@ -32,6 +32,10 @@ struct IgemmParams {
     const float* shift;
     const void* residual;
     const void* mask;
+    // one bit per stored element instead of a 16-bit mask operand: bits_out[(m*NOUT + c) / 8] = which of the 8 outputs of a
+    // chunk are > 0 (written next to a ReLU output); bits_in plays the role of `mask` in a data gradient (1 byte per 16)
+    unsigned char* bits_out;
+    const unsigned char* bits_in;
     float* slab;      // nullable fp32 [M tiles][2][NOUT]: per-workgroup column sums / sums of squares of the
                       // stored output (no atomics; cs_slab_reduce folds the rows afterwards)
     int SH, SW, SC;   // source extents, stored channels
@@ -118,6 +122,7 @@ template <int BM, int BN> struct EpiRegs {
     static constexpr int ITERS = (BM / 2) * BN / 8 / 256;
     uint4 res[2 * ITERS];
     uint4 msk[2 * ITERS];
+    unsigned mbits[2 * ITERS];
 };
 
 template <typename T, int BM, int BN>
@@ -137,6 +142,7 @@ __device__ __forceinline__ void epi_prefetch(const IgemmParams& p, long long m0,
             const long long off = m * p.NOUT + o;          // identity row -> pixel mapping only (dst_step == 1)
             e.res[half * ITERS + it] = (res && ok) ? *reinterpret_cast<const uint4*>(res + off) : make_uint4(0, 0, 0, 0);
             e.msk[half * ITERS + it] = (msk && ok) ? *reinterpret_cast<const uint4*>(msk + off) : make_uint4(0, 0, 0, 0);
+            e.mbits[half * ITERS + it] = (p.bits_in && ok) ? (unsigned)p.bits_in[off >> 3] : 0u;
         }
 }
 
@@ -237,7 +243,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
                 }
-                if (msk) {
+                if (p.bits_in) {
+                    unsigned mb;
+                    if constexpr (PF) mb = pf->mbits[half * ITERS + it];
+                    else mb = p.bits_in[off >> 3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
+                } else if (msk) {
                     float k8[8];
                     if constexpr (PF) unpack_bf16x8(pf->msk[half * ITERS + it], k8);
                     else load8<T>(msk + off, k8);
@@ -245,6 +257,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
                 }
                 store8<T>(dst + off, v);
+                if (p.bits_out) {
+                    unsigned mb = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mb |= (to_f32<T>(from_f32<T>(v[e])) > 0.f ? 1u : 0u) << e;      // sign of the STORED value
+                    // four neighbouring lanes own four consecutive bytes of the same row (NOUT % 32 == 0 keeps the quad inside
+                    // one row and makes this branch quad-uniform): one aligned dword store instead of four byte stores
+                    // (DPP row shifts: lane i takes lane i+1 / i+2 of its 16-lane row; a ds_bpermute shuffle costs an LDS round trip)
+                    mb |= (unsigned)__builtin_amdgcn_mov_dpp((int)mb, 0x101, 0xf, 0xf, true) << 8;      // row_shl:1
+                    mb |= (unsigned)__builtin_amdgcn_mov_dpp((int)mb, 0x102, 0xf, 0xf, true) << 16;     // row_shl:2
+                    if ((tid & 3) == 0) *reinterpret_cast<unsigned*>(p.bits_out + (off >> 3)) = mb;
+                }
                 if (p.slab) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -956,7 +979,7 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     const bool uni1 = g_uni_walk && mode == 1 && p.SCc % 8 == 0 && p.R * p.S <= 32;
     const bool uni0 = g_uni_walk && mode == 0;
     if constexpr (sizeof(T) == 2) {
-        if (dma && mode != 2 && nk_host > 1 && (p.residual || p.mask) && p.dst_step == 1 && g_epi_prefetch) {
+        if (dma && mode != 2 && nk_host > 1 && (p.residual || p.mask || p.bits_in) && p.dst_step == 1 && g_epi_prefetch) {
             if (mode == 0 && uni0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
             else if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
             else if (uni1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
@@ -1062,9 +1085,25 @@ extern "C" size_t cs_conv2d_stats_workspace(long long M, int n_out) {
     return (size_t)((M + 63) / 64 + 4) * 2 * (size_t)n_out * sizeof(float);
 }
 
+static int conv2d_fwd_impl(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
+                           const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
+                           unsigned char* relu_bits, void* stream);
+
 extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
                              const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
                              void* stream) {
+    return conv2d_fwd_impl(g, dtype, x, w_khwc, scale, shift, residual, act, y, stats, workspace, nullptr, stream);
+}
+
+extern "C" int cs_conv2d_fwd_bits(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
+                                  const float* shift, const void* residual, int act, void* y, uint8_t* positive_bits, void* stream) {
+    CS_CHECK_ARG(positive_bits != nullptr, "conv2d_fwd_bits: NULL bit tensor");
+    return conv2d_fwd_impl(g, dtype, x, w_khwc, scale, shift, residual, act, y, nullptr, nullptr, positive_bits, stream);
+}
+
+static int conv2d_fwd_impl(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
+                           const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
+                           unsigned char* relu_bits, void* stream) {
     const int slab = g_next_slab;
     g_next_slab = 0;
     int rc = check_geom(g, dtype);
@@ -1076,6 +1115,8 @@ extern "C" int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     const int ce = dtype == CS_F32 ? 4 : 8;
     p.src = x; p.wgt = w_khwc; p.dst = y;
     p.scale = scale; p.shift = shift; p.residual = residual; p.mask = nullptr;
+    CS_CHECK_ARG(!relu_bits || g->K % 32 == 0, "conv2d_fwd_bits: stored output channels must be a multiple of 32");
+    p.bits_out = relu_bits; p.bits_in = nullptr;
     p.slab = stats ? reinterpret_cast<float*>(workspace) : nullptr;
     p.SH = g->H; p.SW = g->W; p.SC = g->C;
     p.DH = g->P; p.DW = g->Q; p.NOUT = g->K;
@@ -1157,8 +1198,22 @@ extern "C" int cs_fold_partial_rows_batched(const float* const* partial_tab, con
     return CS_OK;
 }
 
+static int conv2d_dgrad_impl(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
+                             const void* mask, const unsigned char* mask_bits, void* dx, float* colsum, void* workspace, void* stream);
+
 extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                                const void* mask, void* dx, float* colsum, void* workspace, void* stream) {
+    return conv2d_dgrad_impl(g, dtype, dy, w_chwk, add, mask, nullptr, dx, colsum, workspace, stream);
+}
+
+extern "C" int cs_conv2d_dgrad_bits(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
+                                    const uint8_t* mask_bits, void* dx, float* colsum, void* workspace, void* stream) {
+    CS_CHECK_ARG(mask_bits != nullptr, "conv2d_dgrad_bits: NULL bit tensor");
+    return conv2d_dgrad_impl(g, dtype, dy, w_chwk, add, nullptr, mask_bits, dx, colsum, workspace, stream);
+}
+
+static int conv2d_dgrad_impl(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
+                             const void* mask, const unsigned char* mask_bits, void* dx, float* colsum, void* workspace, void* stream) {
     const int slab = g_next_slab;
     g_next_slab = 0;
     int rc = check_geom(g, dtype);
@@ -1172,6 +1227,7 @@ extern "C" int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     IgemmParams p{};
     p.src = dy; p.wgt = w_chwk; p.dst = dx;
     p.scale = nullptr; p.shift = nullptr; p.residual = add; p.mask = mask;
+    p.bits_out = nullptr; p.bits_in = mask_bits;
     const bool deferred = !colsum && workspace;
     CS_CHECK_ARG(!deferred || (g->stride == 1 && !slab), "conv2d_dgrad: deferred column sums need a stride-1, ungrouped launch");
     p.slab = (colsum || deferred) ? reinterpret_cast<float*>(workspace) : nullptr;

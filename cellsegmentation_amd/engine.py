@@ -242,6 +242,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
     # train-mode BN bookkeeping for the whole plan in two launches instead of two per layer: one zero-filled fp64 arena for the
     # per-channel statistics, one foreach-add for the num_batches_tracked counters (this path is host-bound: ~1000 launches/step)
     stats_arena, stats_pos, bumped = None, [0], []
+    bits = {}            # slot -> uint8 "output > 0" bit tensor (folded Conv+BN+ReLU outputs of a pass that will run backward)
     if bn_train:
         need = sum(2 * K.pad_channels(u_.conv.out_channels) for u_ in plan.units
                    if u_.kind == "conv" and _bn_uses_batch_stats(u_.bn, bn_train))
@@ -284,6 +285,10 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             if not batch_stats:
                 if stem:
                     y = K.stem_fwd(geom, xp, wp, None, st.shift, u.act)
+                elif save and RELU_BITS and u.act == ACT_RELU and Kp % 32 == 0:
+                    # one bit per output next to the ReLU output: the data gradient that later masks with this tensor reads
+                    # 1 byte per 16 (the bf16 masks are ~1/8 of a training step's HBM traffic)
+                    y, bits[u.dst] = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped, want_bits=True)
                 else:
                     y = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, res, u.act, grouped=u.grouped)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=False, xp=xp)
@@ -365,7 +370,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
         for (ui_, _, _, cp_, kp_, nb_), (w_khwc, w_chwk, scale, shift, rstd) in zip(record, pk.staged):
             pk.by_unit[ui_] = ((cp_, kp_, nb_), SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd))
         packs[dtype] = pk
-    return SimpleNamespace(t=t, aux=aux, in_hw=in_hw)
+    return SimpleNamespace(t=t, aux=aux, in_hw=in_hw, bits=bits)
 
 
 def compute_requires(plan, param_needs, input_needs):
@@ -392,6 +397,7 @@ def _defers(u, a, need, ui):
             and not a.train and not u.grouped and u.bn is not None and u.conv.bias is None)
 
 
+RELU_BITS = os.environ.get("CELLSEG_RELU_BITS", "1") != "0"          # bit masks next to ReLU outputs (0: bf16 tensors as masks)
 STEM_PAIRED = os.environ.get("CELLSEG_STEM_PAIRED", "1") != "0"      # pixel-paired stem (0: the generic 7x7 path, for A/B runs)
 _grad_sink = None
 # batched weight gradients on a second HIP stream, concurrently with the dgrad chain: measured 2 % SLOWER on the ResNet-50 tile step
@@ -616,14 +622,17 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 final = left[u.src] == 0
                 pending = grads.pop(u.src, None)
                 mask = x if (u.src in plan.relu_slots and final) else None
+                mbits = state.bits.get(u.src) if mask is not None else None
+                if mbits is not None:
+                    mask = None
                 if final:
                     # column sums of the finished gradient feed its producer's BN/bias gradients: left as per-workgroup partial
                     # rows where the launch allows it (the batched finalize folds them; one small launch less per layer)
                     cs = take((geom.C,)) if (geom.stride != 1 or u.grouped) else None
                     dx, gsum_cache[u.src] = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs, grouped=u.grouped,
-                                                         defer_colsum=True)
+                                                         defer_colsum=True, mask_bits=mbits)
                 else:
-                    dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, grouped=u.grouped)
+                    dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, grouped=u.grouped, mask_bits=mbits)
                 grads[u.src] = dx
         elif u.kind == "dw":
             if not a.train:

@@ -229,10 +229,21 @@ def _mark_grouped(grouped):
         _lib.load().cs_conv2d_next_is_grouped()
 
 
-def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None, grouped=False):
+def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None, grouped=False,
+             want_bits=False):
+    """want_bits: also return a uint8 [N,P,Q,K/8] tensor with one bit per output element (> 0), the 1-byte-per-16 form of the
+    ReLU mask a later data gradient needs -> (y, bits)."""
     y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
     lib = _lib.load()
     _mark_grouped(grouped)
+    if want_bits:
+        if stats is not None:
+            raise ValueError("conv_fwd: want_bits and stats are separate entry points")
+        bits = torch.empty((geom.N, geom.P, geom.Q, geom.K // 8), dtype=torch.uint8, device=x.device)
+        _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd_bits(
+            ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(bits), _stream()),
+            extra_tensors=int(residual is not None) + 1.0 / (8 * y.element_size())), "conv2d_fwd_bits")
+        return y, bits
     ws = _stats_ws(geom.N * geom.P * geom.Q, geom.K, x.device) if stats is not None else None
     _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd(
         ctypes.byref(geom), _code(x.dtype), _p(x), _p(w_khwc), _p(scale), _p(shift), _p(residual), act, _p(y), _p(stats), _p(ws),
@@ -338,17 +349,23 @@ def colsum_vector(g):
     return g.vector() if isinstance(g, PartialColsum) else g
 
 
-def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False, defer_colsum=False):
+def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False, defer_colsum=False, mask_bits=None):
     """colsum: zeroed fp32 [C] to accumulate the column sums of dx into; or defer_colsum=True (stride 1, ungrouped) to get
-    (dx, PartialColsum) with the fold left to the consumer."""
+    (dx, PartialColsum) with the fold left to the consumer.  mask_bits: uint8 [N,H,W,C/8] from conv_fwd(want_bits=True), used
+    instead of `mask`."""
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
     _mark_grouped(grouped)
     defer = defer_colsum and geom.stride == 1 and not grouped
     ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if (colsum is not None or defer) else None
-    _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
-        ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), None if defer else _p(colsum), _p(ws), _stream()),
-        extra_tensors=int(add is not None) + int(mask is not None)), "conv2d_dgrad")
+    if mask_bits is not None:
+        _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad_bits(
+            ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask_bits), _p(dx), None if defer else _p(colsum), _p(ws),
+            _stream()), extra_tensors=int(add is not None) + 1.0 / (8 * dx.element_size())), "conv2d_dgrad_bits")
+    else:
+        _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad(
+            ctypes.byref(geom), _code(dy.dtype), _p(dy), _p(w_chwk), _p(add), _p(mask), _p(dx), None if defer else _p(colsum), _p(ws), _stream()),
+            extra_tensors=int(add is not None) + int(mask is not None)), "conv2d_dgrad")
     if defer_colsum:
         if defer:
             return dx, PartialColsum(ws, lib.cs_conv2d_dgrad_partial_rows(ctypes.byref(geom)), geom.C)

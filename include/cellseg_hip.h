@@ -134,6 +134,13 @@ int cs_set_igemm_path(int path);
  *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */
 int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                     const void* mask, void* dx, float* colsum, void* workspace, void* stream);
+/* One bit per element instead of a 16-bit mask operand (the ReLU masks are 1/6 of a training step's HBM traffic otherwise):
+ * cs_conv2d_fwd_bits also writes positive_bits[(pixel*K + k) / 8], bit (k % 8) = "the stored y is > 0"; cs_conv2d_dgrad_bits takes
+ * such a tensor (shaped like x: N*H*W*C/8 bytes) in place of `mask`. */
+int cs_conv2d_fwd_bits(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale, const float* shift,
+                       const void* residual, int act, void* y, uint8_t* positive_bits, void* stream);
+int cs_conv2d_dgrad_bits(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
+                         const uint8_t* mask_bits, void* dx, float* colsum, void* workspace, void* stream);
 /* Deferred column sums: with colsum == NULL and workspace != NULL (stride-1, ungrouped launches only) cs_conv2d_dgrad leaves the
  * per-workgroup partial rows in `workspace` -- row r holds the sums of destination-pixel tile r at [r * 2*C + c] -- and skips the
  * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows),
