@@ -256,11 +256,28 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = k8[e] > 0.f ? v[e] : 0.f;
                 }
-                store8<T>(dst + off, v);
-                if (p.bits_out) {
-                    unsigned mb = 0;
+                unsigned mb = 0;
+                if constexpr (sizeof(T) == 2) {
+                    // pack once; the bits come from the packed words (integer compare of a sign-magnitude half shifted to the top)
+                    uint4 o;
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(dst + off) = o;
+                    if (p.bits_out) {
+                        const unsigned wds[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) mb |= (to_f32<T>(from_f32<T>(v[e])) > 0.f ? 1u : 0u) << e;      // sign of the STORED value
+                        for (int i = 0; i < 4; ++i) {
+                            mb |= ((int)(wds[i] << 16) > 0 ? 1u : 0u) << (2 * i);
+                            mb |= ((int)(wds[i] & 0xffff0000u) > 0 ? 1u : 0u) << (2 * i + 1);
+                        }
+                    }
+                } else {
+                    store8<T>(dst + off, v);
+                    if (p.bits_out) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) mb |= (v[e] > 0.f ? 1u : 0u) << e;
+                    }
+                }
+                if (p.bits_out) {
                     // four neighbouring lanes own four consecutive bytes of the same row (NOUT % 32 == 0 keeps the quad inside
                     // one row and makes this branch quad-uniform): one aligned dword store instead of four byte stores
                     // (DPP row shifts: lane i takes lane i+1 / i+2 of its 16-lane row; a ds_bpermute shuffle costs an LDS round trip)
