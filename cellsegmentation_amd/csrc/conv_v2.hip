@@ -1,0 +1,660 @@
+// Second-generation bf16 convolution kernels for gfx950 (CDNA4): forward and data gradient of the stride-1 RxS convolutions
+// and of the 1x1 convolutions that carry the ResNet / ResNeXt trunk (model/resnet.py:20,23,51,53,55 and their autograd
+// backward).  The first generation (conv_igemm.hip) stays for fp32 parity mode and for every shape this file declines.
+//
+// What is different from conv_igemm.hip, and why (profiles/round1_notes.md: MFMA pipe 25 % busy, 15.7 VALU+SALU per MFMA,
+// one barrier per 64-deep K-step, two LDS passes in the epilogue):
+//  * HALO staging.  The workgroup's pixel tile is a run of BM consecutive destination pixels.  For one 64-channel chunk the
+//    source rows that ALL R*S taps of that run touch are fetched ONCE into LDS ("padded-linear" coordinates: one shared run of
+//    zero slots between image rows and between images, so a tap is a constant row shift and padding needs no test), instead
+//    of once per tap: 1.2-1.6x the tile instead of 9x, and ONE barrier per R*S taps.
+//  * Weights never touch LDS.  They are staged in MFMA-fragment order ("packed": one wave-instruction = 1 KiB contiguous =
+//    the 32 x 16 operand of one MFMA), each wave streams the fragments of ITS 32 output channels straight into registers
+//    two tap-steps ahead (no sharing between waves -> no barrier, no ds_write, no ds_read for half of the operands).
+//  * Waves split the OUTPUT CHANNELS (1 x 4), every wave multiplies the whole pixel tile: 128 px x 32 ch per wave = 4 MFMA
+//    32x32x16 per 16-deep step fed by 4 ds_read_b128 + 1/4 buffer_load.
+//  * The accumulator is kept TRANSPOSED (channel on the register index, pixel on the lane): after bf16 packing and one
+//    v_permlane32_swap per dword pair every lane owns 16 contiguous bytes of its pixel's row -> residual / mask-bit loads and
+//    stores go straight between registers and HBM; no LDS pass, no barrier in the epilogue.
+//  * All global->LDS and global->register traffic of the main loop is inline asm with hand-counted s_waitcnt vmcnt(N)
+//    (hipcc drains the queue at every use otherwise, see conv_igemm.hip).
+#include "cs_common.h"
+#include <stdlib.h>
+#include <utility>
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // native vector: a 128-bit register operand of inline asm
+constexpr unsigned OOB = 0x80000000u;
+
+struct C2Params {
+    const void* src;               // NHWC bf16 [NS][SH][SW][SC]
+    const void* wpk;               // packed weights (cs_pack_conv_weights)
+    void* dst;                     // NHWC bf16 [NS][DH][DW][NOUT]
+    const float* shift;            // per destination channel, nullable
+    const void* residual;          // destination-shaped bf16 (forward: residual, data gradient: add), nullable
+    unsigned char* bits_out;       // nullable: one bit per stored element (> 0)
+    const unsigned char* bits_in;  // nullable: one bit per destination element, 0 -> the element is stored as 0
+    float* slab;                   // nullable: per-workgroup partial column sums [rows][2][NOUT]
+    int want_sq;                   // slab also gets sums of squares
+    int act;                       // CS_ACT_NONE / CS_ACT_RELU
+    int SH, SW, SC, NS;
+    int DH, DW, NOUT;
+    int Wp, Hp, PW, PH;            // padded-linear geometry of the source: Wp = SW + PW, Hp = SH + PH
+    int stride;                    // 1x1 kernel only
+    unsigned mg_dw, sh_dw, mg_dh, sh_dh, mg_wp, sh_wp, mg_hp, sh_hp;
+    int NCC;                       // 64-channel chunks of the contraction
+    int n_ntiles;
+    unsigned M;                    // NS*DH*DW
+    unsigned src_bytes;
+    unsigned pix_bytes;            // SC * 2
+    unsigned wpk_bytes;            // whole packed weight tensor (the range check of a raw buffer covers voffset + soffset)
+};
+
+// n / d for n < 2^31, d >= 2: q = umulhi(n, mg) >> sh with mg = floor(2^(31+l) / d) + 1, sh = l - 1, l = ceil(log2 d)
+__device__ __forceinline__ unsigned udivm(unsigned n, unsigned mg, unsigned sh) { return __umulhi(n, mg) >> sh; }
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p; }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// one 16-row LDS block = two 1 KiB LDS-DMA pieces: lanes = 4 chunk columns x 16 rows; the second piece takes the other
+// 64 bytes of every row (scalar offset; out-of-range lanes carry 0x80000000 and stay out of range with any soffset < 2 GiB)
+__device__ __forceinline__ void dma_block(const i32x4& rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+    unsigned tmp;
+    // (no "memory" clobber on purpose: the pieces land in the stage nobody reads until the next raw_barrier(), so the compiler
+    // may keep moving the current stage's ds_reads across this statement)
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_add_u32 %0, %4, 64\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_add_u32 m0, %1, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %0 offen lds"
+        : "=&s"(tmp)
+        : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+        : "scc");
+}
+
+// ---- the main loop owns v[100:255]: the compiler's own allocation is capped at v0..v99 (amdgpu_num_vgpr counts in units of
+// two on gfx950) and NEVER sees a value of the loop.  Why: hipcc may copy, split or rotate an asm OUTPUT between an
+// asm-issued load and our own s_waitcnt (seen: v_mov_b64 of a weight buffer in flight at the loop header), and an
+// `asm volatile` MFMA is a scheduling barrier for the compiler's own ds_reads (seen: every LDS read serialised in front of
+// its MFMA).  A register the compiler never sees can be neither copied nor rescheduled: every instruction of the loop is
+// its own asm statement with compile-time register numbers, in program order.
+//   v[100:103] address temporaries        v[104:111] operand-row addresses (two sets of 4: this tap / next tap)
+//   v[112:143] pixel fragments (two sets of 4 x b128)   v[144:207] accumulators (4 tiles x 16)
+//   v[208:255] weight fragments (three tap-steps in flight x 4 x b128)
+// Audit after every edit: tools/audit_asm.py (no scratch, no compiler instruction naming v100 or above).
+constexpr int R_TMP = 100, R_AD = 104, R_AF = 112, R_ACC = 144, R_B = 208;
+
+__device__ __forceinline__ void own_registers() {
+    // makes the kernel descriptor allocate all 256 registers (inline-asm TEXT is not scanned for register use)
+    asm volatile("; v[100:255] are owned by the main loop" ::: "v100", "v255");
+}
+template <int REG> __device__ __forceinline__ void vzero() { asm volatile("v_mov_b32 v[%c0], 0" ::"i"(REG)); }
+template <int... Rs> __device__ __forceinline__ void vzero_seq(std::integer_sequence<int, Rs...>) { (vzero<R_ACC + Rs>(), ...); }
+
+template <int J>
+__device__ __forceinline__ void bload4(const i32x4& rsrc, unsigned voff, unsigned soff) {
+    // the four 1 KiB weight fragments of one tap-step (64 contraction channels) of this wave's 32 output channels
+    asm volatile("buffer_load_dwordx4 v[%c3:%c4], %0, %1, %2 offen\n\t"
+                 "buffer_load_dwordx4 v[%c5:%c6], %0, %1, %2 offen offset:1024\n\t"
+                 "buffer_load_dwordx4 v[%c7:%c8], %0, %1, %2 offen offset:2048\n\t"
+                 "buffer_load_dwordx4 v[%c9:%c10], %0, %1, %2 offen offset:3072"
+                 ::"v"(voff), "s"(rsrc), "s"(soff), "i"(R_B + 16 * J), "i"(R_B + 16 * J + 3), "i"(R_B + 16 * J + 4), "i"(R_B + 16 * J + 7),
+                 "i"(R_B + 16 * J + 8), "i"(R_B + 16 * J + 11), "i"(R_B + 16 * J + 12), "i"(R_B + 16 * J + 15));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+template <int DST, int ADDR, unsigned OFF> __device__ __forceinline__ void lds_rd() {
+    asm volatile("ds_read_b128 v[%c0:%c1], v[%c2] offset:%c3" ::"i"(DST), "i"(DST + 3), "i"(ADDR), "i"(OFF));
+}
+// acc (channel x pixel) += weight fragment x pixel fragment
+template <int ACC, int B, int A> __device__ __forceinline__ void mfma() {
+    asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], v[%c2:%c3], v[%c4:%c5], v[%c0:%c1]" ::"i"(ACC), "i"(ACC + 15), "i"(B), "i"(B + 3), "i"(A),
+                 "i"(A + 3));
+}
+// operand-row addresses of one tap for the 4 pixel tiles -> address set S (see row_addr; hhb = chunk-column bit of the lane half)
+template <int S>
+__device__ __forceinline__ void addr4(unsigned q0, unsigned q1, unsigned q2, unsigned q3, unsigned sh, unsigned hhb, unsigned cf0) {
+#define CS_ADDR1(Q, A)                                             \
+    "v_add_lshl_u32 v[%c[" A "]], %[" Q "], %[sh], 4\n\t"           \
+    "v_and_b32 v[%c[t]], 0xffffff00, v[%c[" A "]]\n\t"              \
+    "v_and_or_b32 v[%c[" A "]], v[%c[" A "]], %[cf0], %[hhb]\n\t"   \
+    "v_lshl_or_b32 v[%c[" A "]], v[%c[t]], 3, v[%c[" A "]]\n\t"
+    asm volatile(CS_ADDR1("q0", "a0") CS_ADDR1("q1", "a1") CS_ADDR1("q2", "a2") CS_ADDR1("q3", "a3")
+                 ::[q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3), [sh] "s"(sh), [hhb] "v"(hhb), [cf0] "s"(cf0),
+                 [a0] "i"(R_AD + 4 * S), [a1] "i"(R_AD + 4 * S + 1), [a2] "i"(R_AD + 4 * S + 2), [a3] "i"(R_AD + 4 * S + 3), [t] "i"(R_TMP));
+#undef CS_ADDR1
+}
+// one accumulator register into a compiler value (after the loop)
+template <int REG> __device__ __forceinline__ float vget() {
+    float x;
+    asm volatile("v_mov_b32 %0, v[%c1]" : "=v"(x) : "i"(REG));
+    return x;
+}
+template <int I, int... Rs> __device__ __forceinline__ void acc_tile(f32x16& out, std::integer_sequence<int, Rs...>) {
+    ((out[Rs] = vget<R_ACC + 16 * I + Rs>()), ...);
+}
+template <int BASE, int... Rs> __device__ __forceinline__ void dbg_tile(f32x16& out, std::integer_sequence<int, Rs...>) {
+    ((out[Rs] = vget<BASE + Rs>()), ...);
+}
+
+// One tap-step of the 4 x (32 px x 32 ch) wave tile: 16 MFMA, 16 ds_read_b128, software-pipelined over the two fragment sets
+// (set 0: 16-deep steps 0 and 2, set 1: steps 1 and 3).  KIND 0 = first tap of a chunk (cold start: own addresses + first
+// reads), 1 = middle (entered with its first 8 reads in flight, leaves with the next tap's in flight), 2 = last tap of a chunk
+// (no read-ahead: the next chunk's stage is only visible after the barrier).  Every MFMA waits for exactly its own fragment:
+// 7 younger reads outstanding in steady state.
+template <int CUR, int S, unsigned STG, int KIND>
+__device__ __forceinline__ void tap_mfma(unsigned q0, unsigned q1, unsigned q2, unsigned q3, unsigned sh_cur, unsigned sh_next, unsigned hhb,
+                                         unsigned cf0) {
+    constexpr int A = R_AD + 4 * S, N = R_AD + 4 * (1 - S);
+    constexpr int F0 = R_AF, F1 = R_AF + 16;
+    constexpr int B = R_B + 16 * CUR;
+    if constexpr (KIND == 0) {
+        addr4<S>(q0, q1, q2, q3, sh_cur, hhb, cf0);
+        lds_rd<F0 + 0, A + 0, STG>(); lds_rd<F0 + 4, A + 1, STG>(); lds_rd<F0 + 8, A + 2, STG>(); lds_rd<F0 + 12, A + 3, STG>();
+        lds_rd<F1 + 0, A + 0, STG + 512>(); lds_rd<F1 + 4, A + 1, STG + 512>(); lds_rd<F1 + 8, A + 2, STG + 512>(); lds_rd<F1 + 12, A + 3, STG + 512>();
+    }
+    if constexpr (KIND != 2) addr4<1 - S>(q0, q1, q2, q3, sh_next, hhb, cf0);
+    wait_lgkm<7>(); mfma<R_ACC + 0, B + 0, F0 + 0>(); lds_rd<F0 + 0, A + 0, STG + 1024>();
+    wait_lgkm<7>(); mfma<R_ACC + 16, B + 0, F0 + 4>(); lds_rd<F0 + 4, A + 1, STG + 1024>();
+    wait_lgkm<7>(); mfma<R_ACC + 32, B + 0, F0 + 8>(); lds_rd<F0 + 8, A + 2, STG + 1024>();
+    wait_lgkm<7>(); mfma<R_ACC + 48, B + 0, F0 + 12>(); lds_rd<F0 + 12, A + 3, STG + 1024>();
+    wait_lgkm<7>(); mfma<R_ACC + 0, B + 4, F1 + 0>(); lds_rd<F1 + 0, A + 0, STG + 1536>();
+    wait_lgkm<7>(); mfma<R_ACC + 16, B + 4, F1 + 4>(); lds_rd<F1 + 4, A + 1, STG + 1536>();
+    wait_lgkm<7>(); mfma<R_ACC + 32, B + 4, F1 + 8>(); lds_rd<F1 + 8, A + 2, STG + 1536>();
+    wait_lgkm<7>(); mfma<R_ACC + 48, B + 4, F1 + 12>(); lds_rd<F1 + 12, A + 3, STG + 1536>();
+    if constexpr (KIND != 2) {
+        wait_lgkm<7>(); mfma<R_ACC + 0, B + 8, F0 + 0>(); lds_rd<F0 + 0, N + 0, STG>();
+        wait_lgkm<7>(); mfma<R_ACC + 16, B + 8, F0 + 4>(); lds_rd<F0 + 4, N + 1, STG>();
+        wait_lgkm<7>(); mfma<R_ACC + 32, B + 8, F0 + 8>(); lds_rd<F0 + 8, N + 2, STG>();
+        wait_lgkm<7>(); mfma<R_ACC + 48, B + 8, F0 + 12>(); lds_rd<F0 + 12, N + 3, STG>();
+        wait_lgkm<7>(); mfma<R_ACC + 0, B + 12, F1 + 0>(); lds_rd<F1 + 0, N + 0, STG + 512>();
+        wait_lgkm<7>(); mfma<R_ACC + 16, B + 12, F1 + 4>(); lds_rd<F1 + 4, N + 1, STG + 512>();
+        wait_lgkm<7>(); mfma<R_ACC + 32, B + 12, F1 + 8>(); lds_rd<F1 + 8, N + 2, STG + 512>();
+        wait_lgkm<7>(); mfma<R_ACC + 48, B + 12, F1 + 12>(); lds_rd<F1 + 12, N + 3, STG + 512>();
+    } else {
+        wait_lgkm<7>(); mfma<R_ACC + 0, B + 8, F0 + 0>();
+        wait_lgkm<6>(); mfma<R_ACC + 16, B + 8, F0 + 4>();
+        wait_lgkm<5>(); mfma<R_ACC + 32, B + 8, F0 + 8>();
+        wait_lgkm<4>(); mfma<R_ACC + 48, B + 8, F0 + 12>();
+        wait_lgkm<3>(); mfma<R_ACC + 0, B + 12, F1 + 0>();
+        wait_lgkm<2>(); mfma<R_ACC + 16, B + 12, F1 + 4>();
+        wait_lgkm<1>(); mfma<R_ACC + 32, B + 12, F1 + 8>();
+        wait_lgkm<0>(); mfma<R_ACC + 48, B + 12, F1 + 12>();
+    }
+}
+
+// LDS image of one stage: 16-row blocks of 2 KiB, inside a block chunk-major: (row q, 16-byte chunk c) at
+// (q >> 4) * 2048 + c * 256 + (q & 15) * 16.  16 lanes reading 16 consecutive rows of one chunk cover one 256-byte bank row:
+// conflict-free without a row-dependent swizzle, and one DMA piece (4 chunks x 16 rows) reads 16 x 64 contiguous bytes.
+__device__ __forceinline__ unsigned row_addr(unsigned q) {
+    const unsigned t4 = q << 4;
+    return ((t4 & 0xffffff00u) << 3) | (t4 & 0xf0u);
+}
+
+__device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+}
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+    // lanes 32-63 of a <-> lanes 0-31 of b
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
+    const unsigned wds[4] = {o.x, o.y, o.z, o.w};
+    unsigned mb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        mb |= ((int)(wds[i] << 16) > 0 ? 1u : 0u) << (2 * i);
+        mb |= ((int)(wds[i] & 0xffff0000u) > 0 ? 1u : 0u) << (2 * i + 1);
+    }
+    return mb;
+}
+
+// ---- epilogue of one wave: TM pixel tiles (32 pixels each, pixel on the lane) x 32 channels (on the register index) ----
+// acc[i][r]: pixel m0w + 32*i + (lane & 31), channel n_w + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+template <int TM>
+__device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int n_w, unsigned slab_row) {
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float sh[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.shift) s = *reinterpret_cast<const float4*>(p.shift + n_w + 8 * g + 4 * hh);
+        sh[4 * g] = s.x; sh[4 * g + 1] = s.y; sh[4 * g + 2] = s.z; sh[4 * g + 3] = s.w;
+    }
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.residual);
+    bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(p.dst);
+    const unsigned cofs = hh ? 8u : 0u;
+    auto tile = [&]<int I>() {
+        constexpr int i = I;
+        const unsigned m = m0w + 32u * i + (unsigned)l31;
+        const bool ok = m < p.M;
+        const size_t eoff = (size_t)m * (unsigned)p.NOUT + (unsigned)n_w;
+        f32x16 acc;
+        acc_tile<I>(acc, std::make_integer_sequence<int, 16>{});
+#ifdef CS_DEBUG_V2
+        if (p.act == 100) dbg_tile<R_B + 16 * (I % 3)>(acc, std::make_integer_sequence<int, 16>{});        // raw bits of the weight buffers
+        if (p.act == 101) dbg_tile<R_AF + 16 * (I % 2)>(acc, std::make_integer_sequence<int, 16>{});       // pixel fragments
+        if (p.act == 102) dbg_tile<R_TMP>(acc, std::make_integer_sequence<int, 16>{});                     // temporaries + addresses
+#endif
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + sh[r];
+        if (res) {
+            uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                ra = *reinterpret_cast<const uint4*>(res + eoff + cofs);
+                rb = *reinterpret_cast<const uint4*>(res + eoff + 16 + cofs);
+            }
+            // stored arrangement -> accumulator arrangement (the swap is an involution)
+            swap32(ra.x, ra.z); swap32(ra.y, ra.w);
+            swap32(rb.x, rb.z); swap32(rb.y, rb.w);
+            const unsigned rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float lo, hi;
+                unpack2(rw[k], lo, hi);
+                v[2 * k] += lo;
+                v[2 * k + 1] += hi;
+            }
+        }
+        if (p.act == CS_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.bits_in) {
+            const unsigned mb = ok ? reinterpret_cast<const unsigned*>(p.bits_in)[eoff >> 5] : 0u;
+            const unsigned mine = mb >> (4 * hh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = ((mine >> (8 * (r >> 2) + (r & 3))) & 1u) ? v[r] : 0.f;
+        }
+        unsigned pk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        if (p.slab && ok) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float lo, hi;
+                unpack2(pk[k], lo, hi);            // statistics are those of the STORED values
+                s1[2 * k] += lo; s1[2 * k + 1] += hi;
+                s2[2 * k] += lo * lo; s2[2 * k + 1] += hi * hi;
+            }
+        }
+        // groups (0,1) and (2,3): after the swaps lanes 0-31 hold channels 16j .. 16j+7, lanes 32-63 channels 16j+8 .. 16j+15
+        swap32(pk[0], pk[2]); swap32(pk[1], pk[3]);
+        swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
+        const uint4 oa = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        const uint4 ob = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        if (ok) {
+            *reinterpret_cast<uint4*>(dst + eoff + cofs) = oa;
+            *reinterpret_cast<uint4*>(dst + eoff + 16 + cofs) = ob;
+        }
+        if (p.bits_out) {
+            // byte j of the pixel's dword = channels 8j .. 8j+7: this lane owns bytes (hh, 2 + hh)
+            unsigned w = (pos_bits8(oa) | (pos_bits8(ob) << 16)) << (8 * hh);
+            w |= (unsigned)__shfl_xor((int)w, 32, 64);
+            if (ok && hh == 0) reinterpret_cast<unsigned*>(p.bits_out)[eoff >> 5] = w;
+        }
+    };
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (tile.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TM>{});
+    if (p.slab) {
+        // fold the 32 pixels-lanes of each half; lane (l31 == r) keeps channel register r
+        float mine1 = 0.f, mine2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                a += __shfl_xor(a, off, 64);
+                if (p.want_sq) b += __shfl_xor(b, off, 64);
+            }
+            if (l31 == r) { mine1 = a; mine2 = b; }
+        }
+        if (l31 < 16) {
+            const int ch = n_w + 8 * (l31 >> 2) + 4 * hh + (l31 & 3);
+            float* row = p.slab + (size_t)slab_row * 2 * p.NOUT;
+            row[ch] = mine1;
+            row[p.NOUT + ch] = mine2;
+        }
+    }
+}
+
+// =================================================================================================
+// Halo kernel: R x S taps (NTAP = R*S, a multiple of 3; S = SK), stride 1.  Workgroup = 4 waves as WM x WN;
+// wave tile = (32*TM pixels) x 32 channels; NBW = 16-row LDS blocks each wave fetches per 64-channel chunk.
+// =================================================================================================
+template <int NTAP, int SK, int TM, int WM, int WN, int NBW>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void conv2_halo_kernel(C2Params p) {
+    static_assert(WM * WN == 4 && NTAP % 3 == 0 && NBW <= 8, "layout");
+    constexpr int BM = WM * TM * 32, BN = WN * 32;
+    constexpr unsigned STAGE = NBW * 4 * 2048;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    // XCD-aware tile order: id = 8*slot + xcd, all N tiles of one M tile back to back on one XCD (conv_igemm.hip)
+    const unsigned bid = blockIdx.x;
+    const unsigned slot = bid >> 3;
+    const unsigned mtile = (slot / (unsigned)p.n_ntiles) * 8u + (bid & 7u);
+    const unsigned m0 = mtile * BM;
+    if (m0 >= p.M) return;
+    const int n0 = (int)(slot % (unsigned)p.n_ntiles) * BN;
+    const int n_w = n0 + wn * 32;
+    const bool alive = n_w < p.NOUT;
+
+    auto pos0 = [&](unsigned m) -> unsigned {      // padded-linear position of tap offset (0,0) of destination pixel m
+        const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+        const unsigned x = m - yall * (unsigned)p.DW;
+        const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+        const unsigned y = yall - n * (unsigned)p.DH;
+        return (n * (unsigned)p.Hp + y) * (unsigned)p.Wp + x;
+    };
+    const unsigned Lmin = pos0(m0);
+    const unsigned m0w = m0 + (unsigned)(wm * TM * 32);
+    unsigned qb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        unsigned m = m0w + 32u * i + (unsigned)l31;
+        if (m > p.M - 1) m = p.M - 1;
+        qb[i] = pos0(m) - Lmin;
+    }
+    // this wave's LDS blocks: b = wave + 4j; lane -> (row 16b + (lane & 15), chunk column lane >> 4 (+4 for the second piece))
+    unsigned voff[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const unsigned L = Lmin + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+        const unsigned row = udivm(L, p.mg_wp, p.sh_wp);
+        const unsigned col = L - row * (unsigned)p.Wp;
+        const unsigned n = udivm(row, p.mg_hp, p.sh_hp);
+        const unsigned ry = row - n * (unsigned)p.Hp;
+        const bool real = col >= (unsigned)p.PW && ry >= (unsigned)p.PH && n < (unsigned)p.NS;
+        const unsigned pix = (n * (unsigned)p.SH + (ry - (unsigned)p.PH)) * (unsigned)p.SW + (col - (unsigned)p.PW);
+        voff[j] = real ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+    }
+    const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
+    const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
+    const unsigned bvoff = alive ? (unsigned)lane * 16u : OOB;
+    unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)p.NCC * (unsigned)(NTAP * 4096);
+    const unsigned smem_base = lds_off(smem);
+
+    static_assert(TM == 4, "the register map of the main loop is laid out for 4 pixel tiles per wave");
+    own_registers();
+    vzero_seq(std::make_integer_sequence<int, 64>{});
+    const unsigned hhb = (unsigned)hh * 256u;
+    const unsigned cf0 = 0xf0u;
+
+    // ---- prologue: chunk 0 of A, weights of steps 0 and 1
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) dma_block(rsrc_a, smem_base + (unsigned)(wave + 4 * j) * 2048u, voff[j], 0u);
+    bload4<0>(rsrc_b, bvoff, wsoff); wsoff += 4096u;
+    bload4<1>(rsrc_b, bvoff, wsoff); wsoff += 4096u;
+    wait_vm<8>();
+    raw_barrier();
+
+    unsigned nxt_soff = 128u;                    // channel offset (bytes) of the chunk being fetched
+
+    // one tap-step: ODD = the chunk being multiplied sits in stage 1 (and the next one goes to stage 0); HN = a next chunk exists
+    auto tap = [&]<int T, bool ODD, bool HN>() {
+        constexpr int CUR = T % 3, NX2 = (T + 2) % 3;
+        constexpr bool has1 = HN || (T + 1 < NTAP);
+        constexpr bool has2 = HN || (T + 2 < NTAP);
+        constexpr int D0 = (HN && T < NBW) ? 2 : 0;
+        constexpr int D1 = (HN && T >= 1 && T - 1 < NBW) ? 2 : 0;
+        constexpr int D2 = (HN && T >= 2 && T - 2 < NBW) ? 2 : 0;
+        constexpr unsigned CUR_STAGE = ODD ? STAGE : 0u, NXT_STAGE = ODD ? 0u : STAGE;
+        constexpr int KIND = T == 0 ? 0 : (T == NTAP - 1 ? 2 : 1);
+        if constexpr (has2) {
+            bload4<NX2>(rsrc_b, bvoff, wsoff);
+            wsoff += 4096u;
+        }
+        if constexpr (D0) dma_block(rsrc_a, smem_base + NXT_STAGE + (unsigned)(wave + 4 * T) * 2048u, voff[T < NBW ? T : 0], nxt_soff);
+        wait_vm<(has1 ? 4 : 0) + (has2 ? 4 : 0) + D0 + D1 + D2>();
+        const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.Wp + (unsigned)(T % SK);
+        const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.Wp + (unsigned)((T + 1) % SK);
+        tap_mfma<CUR, T & 1, CUR_STAGE, KIND>(qb[0], qb[1], qb[2], qb[3], sh_cur, sh_next, hhb, cf0);
+    };
+    auto chunk = [&]<bool ODD, bool HN>() {
+        [&]<int... Ts>(std::integer_sequence<int, Ts...>) { (tap.template operator()<Ts, ODD, HN>(), ...); }(std::make_integer_sequence<int, NTAP>{});
+    };
+
+    if constexpr (NBW > 5) {
+        chunk.template operator()<false, false>();         // single-chunk launches only (one 64 KiB stage)
+    } else {
+        for (int cc = 0; cc < p.NCC; cc += 2) {
+            if (cc) { raw_barrier(); nxt_soff += 128u; }      // every wave's pieces of this chunk landed (its own tap waits), the previous one is read out
+            if (cc + 1 < p.NCC) chunk.template operator()<false, true>();
+            else chunk.template operator()<false, false>();
+            if (cc + 1 < p.NCC) {
+                raw_barrier();
+                nxt_soff += 128u;
+                if (cc + 2 < p.NCC) chunk.template operator()<true, true>();
+                else chunk.template operator()<true, false>();
+            }
+        }
+    }
+    // MFMA results -> VALU readers: the hazard padding hipcc would insert for its own MFMAs
+    asm volatile("s_nop 15\n\ts_nop 15");
+    if (!alive) return;
+    epilogue_t<TM>(p, m0w, n_w, mtile * WM + wm);
+}
+
+// ---- weights [ROWS][taps][COLS] bf16 (ROWS = destination channels, COLS = contraction channels, both staged layouts of
+// cs_weight_prep have this shape) -> MFMA-fragment order [row tile 32][chunk 64][tap][k16][lane][8]; flip = taps mirrored
+// (data gradient).  One thread per 16 bytes.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int rows, int cols, int R, int S,
+                                                           int flip, long long total) {
+    const int ntap = R * S, ncc = cols / 64;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int lane = (int)(idx & 63);
+        long long u = idx >> 6;
+        const int k16 = (int)(u & 3); u >>= 2;
+        const int t = (int)(u % ntap); u /= ntap;
+        const int cc = (int)(u % ncc);
+        const int rt = (int)(u / ncc);
+        const int row = rt * 32 + (lane & 31);
+        const int col = cc * 64 + k16 * 16 + 8 * (lane >> 5);
+        const int ts = flip ? ntap - 1 - t : t;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < rows) v = w[(((long long)row * ntap + ts) * cols + col) >> 3];
+        out[idx] = v;
+    }
+}
+
+void magic(unsigned d, unsigned& mg, unsigned& sh) {
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    const unsigned long long two_p = 1ull << (31 + l);
+    mg = (unsigned)(two_p / d + 1ull);
+    sh = (unsigned)(l - 1);
+}
+
+// geometry of the packed-operand launch; cfg: 0 = not served, 1 = 128 px x 128 ch (1x4 waves), 2 = 256 px x 64 ch (2x2 waves)
+struct C2Plan {
+    int cfg, nbw, ncc, rows;       // rows = partial column-sum rows
+    C2Params p;
+};
+
+const bool g_v2_off = [] { const char* e = getenv("CELLSEG_NO_V2"); return e && atoi(e); }();
+
+bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
+    if (g_v2_off) return false;
+    if (g->R != 3 || g->S != 3 || g->stride != 1 || g->pad < 0 || g->pad > 2) return false;
+    const int SC = dgrad ? g->K : g->C, NOUT = dgrad ? g->C : g->K;
+    const int SH = dgrad ? g->P : g->H, SW = dgrad ? g->Q : g->W;
+    const int DH = dgrad ? g->H : g->P, DW = dgrad ? g->W : g->Q;
+    if (SC % 64 || NOUT % 64 || DH < 2 || DW < 2 || SH < 1 || SW < 1) return false;
+    const int PWH = dgrad ? g->R - 1 - g->pad : g->pad;
+    if (PWH < 0) return false;
+    const long long M = (long long)g->N * DH * DW;
+    const unsigned long long src_bytes = (unsigned long long)g->N * SH * SW * SC * 2ull;
+    if (M >= (1ll << 31) - 512 || src_bytes >= 0x80000000ull || (unsigned long long)M * NOUT * 2ull >= (1ull << 40)) return false;
+    const int Wp = SW + PWH, Hp = SH + PWH;
+    if (Wp < 2 || Hp < 2 || Wp < DW || Hp < DH) return false;
+    if ((long long)g->N * Hp * Wp + 4096 >= (1ll << 31)) return false;
+    const int ncc = SC / 64;
+    auto window_blocks = [&](int BM) {
+        const long long span = (BM - 1) + (long long)cs_ceil_div(BM - 1, DW) * (Wp - DW) + (long long)cs_ceil_div(BM - 1, (long long)DH * DW) * ((long long)(Hp - DH) * Wp);
+        const long long rows = span + (long long)(g->R - 1) * Wp + (g->S - 1) + 1;
+        return (int)((rows + 15) / 16);
+    };
+    int cfg = 0, nbw = 0;
+    if (NOUT % 128 == 0) {
+        const int nb = (window_blocks(128) + 3) / 4;
+        if (ncc == 1 ? nb <= 8 : nb <= 5) { cfg = 1; nbw = nb < 3 ? 3 : nb; }
+    } else if (NOUT == 64 && ncc == 1) {
+        const int nb = (window_blocks(256) + 3) / 4;
+        if (nb <= 8) { cfg = 2; nbw = 8; }
+    }
+    if (!cfg) return false;
+    if (cfg == 1 && ncc == 1 && nbw > 5) nbw = 8;
+    C2Params& p = pl.p;
+    p = C2Params{};
+    p.SH = SH; p.SW = SW; p.SC = SC; p.NS = g->N;
+    p.DH = DH; p.DW = DW; p.NOUT = NOUT;
+    p.Wp = Wp; p.Hp = Hp; p.PW = PWH; p.PH = PWH;
+    p.stride = 1;
+    magic((unsigned)DW, p.mg_dw, p.sh_dw);
+    magic((unsigned)DH, p.mg_dh, p.sh_dh);
+    magic((unsigned)Wp, p.mg_wp, p.sh_wp);
+    magic((unsigned)Hp, p.mg_hp, p.sh_hp);
+    p.NCC = ncc;
+    p.M = (unsigned)M;
+    p.src_bytes = (unsigned)src_bytes;
+    p.pix_bytes = (unsigned)SC * 2u;
+    const unsigned long long wbytes = (unsigned long long)cs_ceil_div(NOUT, 32) * 32 * g->R * g->S * (unsigned long long)SC * 2ull;
+    if (wbytes >= 0x80000000ull) return false;
+    p.wpk_bytes = (unsigned)wbytes;
+    const int BM = cfg == 1 ? 128 : 256, BN = cfg == 1 ? 128 : 64;
+    p.n_ntiles = cs_ceil_div(NOUT, BN);
+    pl.cfg = cfg; pl.nbw = nbw; pl.ncc = ncc;
+    pl.rows = cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
+    return true;
+}
+
+template <int NBW>
+int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
+    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 128);
+    dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
+    const size_t lds = (size_t)NBW * 8192 * (two_stage ? 2 : 1);
+    auto fn = conv2_halo_kernel<9, 3, 4, 1, 4, NBW>;
+    if (lds > 65536) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) {
+                cs_set_error_("conv2: cannot raise the dynamic LDS limit");
+                return CS_ERR_LAUNCH;
+            }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+int launch_halo(const C2Plan& pl, hipStream_t st) {
+    const C2Params& p = pl.p;
+    if (pl.cfg == 2) {
+        const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 256);
+        dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
+        hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8>), grid, dim3(256), 8 * 8192, st, p);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
+    const int two = pl.ncc > 1;
+    switch (pl.nbw) {
+        case 3: return launch_cfg1<3>(p, st, two);
+        case 4: return launch_cfg1<4>(p, st, two);
+        case 5: return launch_cfg1<5>(p, st, two);
+        default: return launch_cfg1<8>(p, st, 0);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int cs_conv2d_packed_supported(const CsConvGeom* g, int dgrad) {
+    if (!g) return 0;
+    C2Plan pl;
+    return plan_halo(g, dgrad, pl) ? 1 : 0;
+}
+
+extern "C" size_t cs_conv2d_packed_weight_bytes(const CsConvGeom* g, int dgrad) {
+    if (!g) return 0;
+    const int rows = dgrad ? g->C : g->K, cols = dgrad ? g->K : g->C;
+    return (size_t)cs_ceil_div(rows, 32) * 32 * g->R * g->S * (size_t)cols * 2;
+}
+
+extern "C" int cs_pack_conv_weights(const CsConvGeom* g, int dgrad, const void* w_staged, void* w_packed, void* stream) {
+    CS_CHECK_ARG(g && w_staged && w_packed, "pack_conv_weights: NULL argument");
+    const int rows = dgrad ? g->C : g->K, cols = dgrad ? g->K : g->C;
+    CS_CHECK_ARG(cols % 64 == 0 && rows % 8 == 0, "pack_conv_weights: contraction channels must be a multiple of 64");
+    const long long total = (long long)cs_ceil_div(rows, 32) * (cols / 64) * g->R * g->S * 4 * 64;
+    long long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint4*>(w_staged),
+                       reinterpret_cast<uint4*>(w_packed), rows, cols, g->R, g->S, dgrad ? 1 : 0, total);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_conv2d_packed_partial_rows(const CsConvGeom* g, int dgrad) {
+    C2Plan pl;
+    if (!g || !plan_halo(g, dgrad, pl)) return 0;
+    return pl.rows;
+}
+
+extern "C" int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const void* w_packed, const float* shift, const void* residual, int act,
+                                    void* y, uint8_t* positive_bits, void* stream) {
+    CS_CHECK_ARG(g && x && w_packed && y, "conv2d_fwd_packed: NULL tensor");
+#ifndef CS_DEBUG_V2
+    CS_CHECK_ARG(act == CS_ACT_NONE || act == CS_ACT_RELU, "conv2d_fwd_packed: activation must be none or ReLU");
+#endif
+    C2Plan pl;
+    if (!plan_halo(g, 0, pl)) {
+        cs_set_error_("conv2d_fwd_packed: geometry not served by the packed-operand kernel (ask cs_conv2d_packed_supported first)");
+        return CS_ERR_UNSUPPORTED;
+    }
+    pl.p.src = x; pl.p.wpk = w_packed; pl.p.dst = y;
+    pl.p.shift = shift; pl.p.residual = residual; pl.p.act = act;
+    pl.p.bits_out = positive_bits;
+    return launch_halo(pl, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, const uint8_t* mask_bits,
+                                      void* dx, float* partial_rows, void* stream) {
+    CS_CHECK_ARG(g && dy && w_packed && dx, "conv2d_dgrad_packed: NULL tensor");
+    C2Plan pl;
+    if (!plan_halo(g, 1, pl)) {
+        cs_set_error_("conv2d_dgrad_packed: geometry not served by the packed-operand kernel (ask cs_conv2d_packed_supported first)");
+        return CS_ERR_UNSUPPORTED;
+    }
+    pl.p.src = dy; pl.p.wpk = w_packed; pl.p.dst = dx;
+    pl.p.residual = add; pl.p.act = CS_ACT_NONE;
+    pl.p.bits_in = mask_bits;
+    pl.p.slab = partial_rows;
+    return launch_halo(pl, reinterpret_cast<hipStream_t>(stream));
+}

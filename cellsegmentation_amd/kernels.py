@@ -251,6 +251,46 @@ def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_
     return y
 
 
+# ---------------------------------------------------------------- packed-operand bf16 convolutions (csrc/conv_v2.hip)
+def packed_supported(geom, dtype, dgrad=False):
+    """Does the halo-tile / packed-weight kernel serve this geometry (bf16 only)?"""
+    return dtype == torch.bfloat16 and bool(_lib.load().cs_conv2d_packed_supported(ctypes.byref(geom), 1 if dgrad else 0))
+
+
+def pack_conv_weights(geom, w_staged, dgrad=False, out=None):
+    """staged w_khwc (forward) / w_chwk (data gradient) -> MFMA-fragment order (a flat bf16 tensor)."""
+    lib = _lib.load()
+    n = lib.cs_conv2d_packed_weight_bytes(ctypes.byref(geom), 1 if dgrad else 0) // 2
+    if out is None:
+        out = torch.empty((n,), dtype=torch.bfloat16, device=w_staged.device)
+    _lib.check(lib.cs_pack_conv_weights(ctypes.byref(geom), 1 if dgrad else 0, _p(w_staged), _p(out), _stream()), "pack_conv_weights")
+    return out
+
+
+def conv_fwd_packed(geom, x, w_packed, shift=None, residual=None, act=CS_ACT_NONE, want_bits=False, out=None):
+    y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
+    bits = torch.empty((geom.N, geom.P, geom.Q, geom.K // 8), dtype=torch.uint8, device=x.device) if want_bits else None
+    lib = _lib.load()
+    _lib.check(_timed("fwd", geom, x.dtype, lambda: lib.cs_conv2d_fwd_packed(
+        ctypes.byref(geom), _p(x), _p(w_packed), _p(shift), _p(residual), act, _p(y), _p(bits), _stream()),
+        extra_tensors=int(residual is not None) + (1.0 / 16 if want_bits else 0.0)), "conv2d_fwd_packed")
+    return (y, bits) if want_bits else y
+
+
+def conv_dgrad_packed(geom, dy, w_packed, add=None, mask_bits=None, want_colsum=False):
+    """-> dx, or (dx, PartialColsum) with want_colsum."""
+    dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
+    lib = _lib.load()
+    rows = lib.cs_conv2d_packed_partial_rows(ctypes.byref(geom), 1) if want_colsum else 0
+    ws = torch.empty((rows, 2 * geom.C), dtype=torch.float32, device=dy.device) if want_colsum else None
+    _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad_packed(
+        ctypes.byref(geom), _p(dy), _p(w_packed), _p(add), _p(mask_bits), _p(dx), _p(ws), _stream()),
+        extra_tensors=int(add is not None) + (1.0 / 16 if mask_bits is not None else 0.0)), "conv2d_dgrad_packed")
+    if want_colsum:
+        return dx, PartialColsum(ws, rows, geom.C)
+    return dx
+
+
 # ---------------------------------------------------------------- stem on a pixel-paired image (cs_stem_*)
 def is_stem_geom(geom):
     """Conv2d(3 -> K, 7x7, stride 2, padding 3) on an NHWC8 image: the layer the paired path replaces."""

@@ -297,6 +297,27 @@ int cs_segmented_topk(const float* probs, const int32_t* groups, const int32_t* 
                       const int64_t* seg_offsets, int n_groups, int max_run, long long T, int64_t* out_idx,
                       int64_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- packed-operand bf16 convolutions (csrc/conv_v2.hip): the stride-1 3x3 forward / data gradient of BasicBlock / Bottleneck
+ * (model/resnet.py:20,23,53 and their autograd backward) with the source rows of ALL taps staged once per 64-channel chunk (halo
+ * tile in LDS), weights streamed to registers in MFMA-fragment order and a register-direct epilogue.  CS_BF16 only.
+ *   cs_conv2d_packed_supported : 1 when the geometry is served (3x3, stride 1, channel counts multiples of 64, operand < 2 GiB, ...);
+ *                                otherwise use cs_conv2d_fwd / cs_conv2d_dgrad with the plain staged weights.  dgrad: 0 = forward, 1 = data gradient.
+ *   cs_pack_conv_weights       : staged weights (w_khwc for forward, w_chwk for the data gradient, as cs_weight_prep /
+ *                                cs_stage_conv_bn* write them) -> fragment order [32-row tile][64-ch chunk][tap][16-deep step][lane][8],
+ *                                cs_conv2d_packed_weight_bytes() bytes; the data-gradient form mirrors the taps.
+ *   cs_conv2d_fwd_packed       : y = act(conv(x, w) + shift[k] + residual); positive_bits (nullable) as cs_conv2d_fwd_bits.
+ *   cs_conv2d_dgrad_packed     : dx = (conv_transpose(dy, w) + add) masked by mask_bits (nullable, as cs_conv2d_dgrad_bits);
+ *                                partial_rows (nullable): fp32 [cs_conv2d_packed_partial_rows(g, 1)][2][C] per-workgroup column
+ *                                sums of the stored dx (first C entries of a row), folded by cs_fold_partial_rows*. */
+int cs_conv2d_packed_supported(const CsConvGeom* g, int dgrad);
+size_t cs_conv2d_packed_weight_bytes(const CsConvGeom* g, int dgrad);
+int cs_pack_conv_weights(const CsConvGeom* g, int dgrad, const void* w_staged, void* w_packed, void* stream);
+int cs_conv2d_packed_partial_rows(const CsConvGeom* g, int dgrad);
+int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const void* w_packed, const float* shift, const void* residual, int act,
+                         void* y, uint8_t* positive_bits, void* stream);
+int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, const uint8_t* mask_bits,
+                           void* dx, float* partial_rows, void* stream);
+
 /* ---- stem on a pixel-paired image (Conv2d(3, 64, 7, stride 2, padding 3), model/resnet.py:111) ---------------------------
  * With 3 channels padded to one 16-byte chunk per pixel the implicit GEMM walks 49 chunks of which 147/392 elements are real.
  * Two neighbouring pixels x 4 channels per chunk make it a 7x4-tap convolution over x_pair[N][H][ceil(W/2)][8] (row stride 2,

@@ -1,0 +1,124 @@
+"""GPU parity of the packed-operand bf16 convolutions (csrc/conv_v2.hip: halo-tile 3x3 forward / data gradient) through the C
+ABI, against torch's CPU fp32 conv on the same bf16-rounded inputs (model/resnet.py:20,23,53 are the layers served).
+
+Tolerance: inputs are pre-rounded to bf16, so the differences are fp32 accumulation order and the final bf16 rounding of the stored
+result: 1e-2 relative to max|ref| (the bound of tests/test_conv_kernels_gpu.py).  Bit tensors and masks are exact.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import kernels as K  # noqa: E402
+
+BF = torch.bfloat16
+TOL = 1e-2
+
+#        N   H   W  Cin Cout pad   (3x3, stride 1)
+SHAPES = [
+    (2, 19, 19, 64, 128, 1),      # one chunk, window blocks: cold start + last tap only
+    (3, 10, 10, 128, 128, 1),     # two chunks, tiles straddle images (100 px per image)
+    (2, 38, 38, 128, 256, 1),     # two N tiles
+    (1, 19, 19, 256, 128, 1),     # four chunks: both stages, odd/even chunk bodies
+    (2, 75, 75, 64, 64, 1),       # 256 x 64 tile configuration (2 x 2 waves), M tail
+    (5, 7, 9, 64, 128, 1),        # non-square, tiny images
+    (2, 12, 12, 64, 128, 0),      # valid convolution: the data gradient's source is smaller than its destination
+    (2, 9, 9, 64, 128, 2),        # pad 2: output larger than input
+    (3, 21, 17, 192, 128, 1),     # three chunks
+]
+
+
+def _q(t):
+    return t.to(BF).float()
+
+
+def _nhwc(t_nchw, dev):
+    return t_nchw.permute(0, 2, 3, 1).contiguous().to(BF).to(dev)
+
+
+def _from_nhwc(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _unpack_bits(bits, C):
+    """uint8 [N,H,W,C/8] -> bool [N,C,H,W]"""
+    b = bits.cpu()
+    sh = torch.arange(8, dtype=torch.uint8)
+    out = ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(*b.shape[:-1], C)
+    return out.permute(0, 3, 1, 2)
+
+
+def _pack_bits(mask_nchw, dev):
+    """bool [N,C,H,W] -> uint8 [N,H,W,C/8]"""
+    m = mask_nchw.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+    m = m.reshape(*m.shape[:-1], m.shape[-1] // 8, 8)
+    w = (m << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    return w.to(dev)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_packed_fwd_and_dgrad(shape, dev):
+    N, H, W, Cin, Cout, pad = shape
+    g = torch.Generator().manual_seed(77 + H * 3 + Cin + Cout)
+    x = _q(torch.randn((N, Cin, H, W), generator=g))
+    w = _q(torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5)
+    geom = K.make_geom(N, H, W, Cin, Cout, 3, 3, 1, pad)
+    P, Q = geom.P, geom.Q
+    w_khwc, w_chwk = K.weight_prep(w.to(dev), None, BF, Cin, Cout, want_fwd=True, want_bwd=True)
+
+    # ---------- forward
+    if K.packed_supported(geom, BF, dgrad=False):
+        shift = torch.randn((Cout,), generator=g) * 0.1
+        res = _q(torch.randn((N, Cout, P, Q), generator=g))
+        ref = F.conv2d(x, w, padding=pad)
+        ref_full = torch.relu(ref + shift.view(1, -1, 1, 1) + res)
+        xd = _nhwc(x, dev)
+        wp = K.pack_conv_weights(geom, w_khwc, dgrad=False)
+        y_plain = K.conv_fwd_packed(geom, xd, wp)
+        y_full, bits = K.conv_fwd_packed(geom, xd, wp, shift.to(dev), _nhwc(res, dev), K.CS_ACT_RELU, want_bits=True)
+        torch.cuda.synchronize()
+        assert _relerr(_from_nhwc(y_plain), ref) < TOL
+        assert _relerr(_from_nhwc(y_full), ref_full) < TOL
+        # the bit tensor is exactly "stored value > 0"
+        assert torch.equal(_unpack_bits(bits, Cout), _from_nhwc(y_full) > 0)
+        # ... and the legacy kernel agrees to rounding (same operands, different summation order)
+        y_old = K.conv_fwd(geom, xd, w_khwc)
+        torch.cuda.synchronize()
+        assert _relerr(_from_nhwc(y_plain), _from_nhwc(y_old)) < TOL
+    else:
+        assert Cout % 64 != 0 or Cin % 64 != 0 or (Cout == 64 and Cin > 64), f"{shape}: forward unexpectedly not served"
+
+    # ---------- data gradient
+    if K.packed_supported(geom, BF, dgrad=True):
+        dy = _q(torch.randn((N, Cout, P, Q), generator=g))
+        add = _q(torch.randn((N, Cin, H, W), generator=g))
+        mask = torch.rand((N, Cin, H, W), generator=g) > 0.4
+        ref_dx = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, stride=1, padding=pad)
+        ref_dx2 = (ref_dx + add) * mask
+        dyd = _nhwc(dy, dev)
+        wpd = K.pack_conv_weights(geom, w_chwk, dgrad=True)
+        dx = K.conv_dgrad_packed(geom, dyd, wpd)
+        dx2, pc = K.conv_dgrad_packed(geom, dyd, wpd, add=_nhwc(add, dev), mask_bits=_pack_bits(mask, dev), want_colsum=True)
+        cs = pc.vector()
+        torch.cuda.synchronize()
+        assert _relerr(_from_nhwc(dx), ref_dx) < TOL
+        assert _relerr(_from_nhwc(dx2), ref_dx2) < TOL
+        assert bool((_from_nhwc(dx2)[~mask] == 0).all()), "masked elements must be stored as exact zeros"
+        ref_cs = dx2.float().sum(dim=(0, 1, 2)).cpu()
+        assert _relerr(cs.cpu(), ref_cs) < 1e-3
+
+
+def test_packed_declines_what_it_does_not_serve(dev):
+    assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 2, 1), BF)          # stride 2
+    assert not K.packed_supported(K.make_geom(2, 19, 19, 24, 128, 3, 3, 1, 1), BF)          # channels not a multiple of 64
+    assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 1, 1), torch.float32)
+    assert not K.packed_supported(K.make_geom(2, 1, 1, 64, 128, 3, 3, 1, 1), BF)            # 1x1 images (32x32 tiles at layer4)
+    geom = K.make_geom(2, 19, 19, 24, 128, 3, 3, 1, 1)
+    x = torch.zeros((2, 19, 19, 24), dtype=BF, device=dev)
+    with pytest.raises(RuntimeError, match="not served"):
+        K.conv_fwd_packed(geom, x, torch.zeros((16,), dtype=BF, device=dev))

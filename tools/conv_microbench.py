@@ -40,9 +40,19 @@ def main():
         shift = torch.zeros((Kc,), device=dev)
         flops = 2.0 * N * g.P * g.Q * Kc * C * R * R
         res = {}
-        for kind, fn in (("fwd", lambda: K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_RELU)),
-                         ("dgrad", lambda: K.conv_dgrad(g, dy, wc, None, x)),
-                         ("wgrad", lambda: K.conv_wgrad(g, x, dy, raw))):
+        cases = [("fwd", lambda: K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_RELU)),
+                 ("dgrad", lambda: K.conv_dgrad(g, dy, wc, None, x)),
+                 ("wgrad", lambda: K.conv_wgrad(g, x, dy, raw))]
+        if os.environ.get("ONLY"):
+            cases = [c for c in cases if c[0] in os.environ["ONLY"].split(",")]
+        if dt == torch.bfloat16 and K.packed_supported(g, dt, False):
+            wpk = K.pack_conv_weights(g, wk, False)
+            cases.append(("fwd_pk", lambda: K.conv_fwd_packed(g, x, wpk, shift, None, K.CS_ACT_RELU, want_bits=True)))
+        if dt == torch.bfloat16 and K.packed_supported(g, dt, True):
+            wpd = K.pack_conv_weights(g, wc, True)
+            mb = torch.randint(0, 255, (N, H, W, C // 8), dtype=torch.uint8, device=dev)
+            cases.append(("dgrad_pk", lambda: K.conv_dgrad_packed(g, dy, wpd, None, mb, want_colsum=True)))
+        for kind, fn in cases:
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
