@@ -21,7 +21,7 @@ class CsConvGeom(Structure):
 class CsStageDesc(Structure):
     """One layer of cs_stage_conv_bn_multi (include/cellseg_hip.h)."""
     _fields_ = ([(n, c_void_p) for n in ("w", "gamma", "beta", "mean", "var", "conv_bias", "w_khwc", "w_chwk", "scale", "shift", "rstd")]
-                + [("eps", c_float)] + [(n, c_int32) for n in ("K", "Cin", "R", "S", "Cp", "Kp", "block0")])
+                + [("eps", c_float)] + [(n, c_int32) for n in ("K", "Cin", "R", "S", "Cp", "Kp", "block0", "fwd_packed", "bwd_packed")])
 
 
 class CellsegLibraryMissing(RuntimeError):
@@ -33,6 +33,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "cs_abi_version": (c_int, []),
     "cs_last_error": (c_char_p, []),
+    "cs_last_conv_variant": (c_char_p, []),
     "cs_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_nhwc_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_bn_fold": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, _P]),

@@ -20,6 +20,8 @@
 // Epilogue: accumulators -> LDS (fp32) -> 8 channels per thread, fully vectorised
 // scale/shift/residual/activation/mask + store + optional per-channel statistics.
 #include "cs_common.h"
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -911,6 +913,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// name of the kernel instantiation this thread launched last (cs_last_conv_variant): bench.py / tools/check_bench_vs_profile.py
+// key the roofline on it instead of re-deriving the dispatcher's choice
+template <typename T> const char* tname() { return sizeof(T) == 2 ? "bf16" : "f32"; }
+void note_variant(const char* fmt, ...) {
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    cs_set_variant_(buf);
+}
+
 thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
 int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
                             // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
@@ -956,8 +970,8 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
         const bool uni = g_uni_walk && q.SCc % 8 == 0;       // every class has R*S <= 4 taps here
         const unsigned long long sb = (unsigned long long)q.src_pixels * q.SC * sizeof(T);
         const unsigned long long wb = (unsigned long long)q.NOUT * q.wrow_chunks * 16ull;
-        if (uni) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, true>), dim3(b0), dim3(256), clds, st, q, (unsigned)sb, (unsigned)wb);
-        else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, false>), dim3(b0), dim3(256), clds, st, q, (unsigned)sb, (unsigned)wb);
+        if (uni) { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,true>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, true>), dim3(b0), dim3(256), clds, st, q, (unsigned)sb, (unsigned)wb); }
+        else { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,false>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, false>), dim3(b0), dim3(256), clds, st, q, (unsigned)sb, (unsigned)wb); }
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
@@ -984,10 +998,10 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
         };
         if (nk_host <= 1) {
             if (raise(reinterpret_cast<const void*>(&igemm_stream_kernel<T, BM, BN, 1>)) != CS_OK) return CS_ERR_LAUNCH;
-            hipLaunchKernelGGL((igemm_stream_kernel<T, BM, BN, 1>), sgrid, dim3(256), slds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes, n_mtiles);
+            { note_variant("igemm_stream_kernel<%s,%d,%d,1>", tname<T>(), BM, BN); hipLaunchKernelGGL((igemm_stream_kernel<T, BM, BN, 1>), sgrid, dim3(256), slds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes, n_mtiles); }
         } else {
             if (raise(reinterpret_cast<const void*>(&igemm_stream_kernel<T, BM, BN, 2>)) != CS_OK) return CS_ERR_LAUNCH;
-            hipLaunchKernelGGL((igemm_stream_kernel<T, BM, BN, 2>), sgrid, dim3(256), slds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes, n_mtiles);
+            { note_variant("igemm_stream_kernel<%s,%d,%d,2>", tname<T>(), BM, BN); hipLaunchKernelGGL((igemm_stream_kernel<T, BM, BN, 2>), sgrid, dim3(256), slds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes, n_mtiles); }
         }
         CS_LAUNCH_CHECK();
         return CS_OK;
@@ -997,31 +1011,31 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     const bool uni0 = g_uni_walk && mode == 0;
     if constexpr (sizeof(T) == 2) {
         if (dma && mode != 2 && nk_host > 1 && (p.residual || p.mask || p.bits_in) && p.dst_step == 1 && g_epi_prefetch) {
-            if (mode == 0 && uni0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
-            else if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
-            else if (uni1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
-            else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+            if (mode == 0 && uni0) { note_variant("igemm_dma_kernel<%s,%d,%d,%d,true,true>", tname<T>(), BM, BN, 0); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); }
+            else if (mode == 0) { note_variant("igemm_dma_kernel<%s,%d,%d,%d,true,false>", tname<T>(), BM, BN, 0); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); }
+            else if (uni1) { note_variant("igemm_dma_kernel<%s,%d,%d,%d,true,true>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); }
+            else { note_variant("igemm_dma_kernel<%s,%d,%d,%d,true,false>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); }
             CS_LAUNCH_CHECK();
             return CS_OK;
         }
     }
     if (dma && ((mode == 0 && uni0) || uni1)) {
-        if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, false, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
-        else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes);
+        if (mode == 0) { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,true>", tname<T>(), BM, BN, 0); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0, false, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); }
+        else { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,true>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1, false, true>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); }
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
     if (dma) {
         switch (mode) {
-            case 0: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
-            case 1: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
-            default: hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); break;
+            case 0: { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,false>", tname<T>(), BM, BN, 0); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); } break;
+            case 1: { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,false>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); } break;
+            default: { note_variant("igemm_dma_kernel<%s,%d,%d,%d,false,false>", tname<T>(), BM, BN, 2); hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p, (unsigned)src_bytes, (unsigned)wgt_bytes); } break;
         }
     } else {
         switch (mode) {
-            case 0: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p); break;
-            case 1: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p); break;
-            default: hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p); break;
+            case 0: { note_variant("igemm_kernel<%s,%d,%d,%d>", tname<T>(), BM, BN, 0); hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 0>), grid, dim3(256), lds, st, p); } break;
+            case 1: { note_variant("igemm_kernel<%s,%d,%d,%d>", tname<T>(), BM, BN, 1); hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 1>), grid, dim3(256), lds, st, p); } break;
+            default: { note_variant("igemm_kernel<%s,%d,%d,%d>", tname<T>(), BM, BN, 2); hipLaunchKernelGGL((igemm_kernel<T, BM, BN, 2>), grid, dim3(256), lds, st, p); } break;
         }
     }
     CS_LAUNCH_CHECK();
@@ -1854,6 +1868,7 @@ int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
 #define CS_WGRAD_DMA(NST_, BKP_) \
     do { \
         constexpr size_t stage_ = (size_t)BKP_ * (BM + 128) * 2; \
+        note_variant("wgrad_dma_kernel<%d,%d,%s,%d>", BM, NST_, plain ? "true" : "false", BKP_); \
         if (plain) hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, true, BKP_>), grid, dim3(256), NST_ * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
         else hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, false, BKP_>), grid, dim3(256), NST_ * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
     } while (0)
@@ -1866,6 +1881,7 @@ int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
             return CS_OK;
         }
     }
+    note_variant("wgrad_kernel<%s,%d,%d,%s>", tname<T>(), BM, BN, TR ? "true" : "false");
     hipLaunchKernelGGL((wgrad_kernel<T, BM, BN, TR>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;

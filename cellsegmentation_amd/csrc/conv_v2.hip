@@ -19,6 +19,7 @@
 //  * All global->LDS and global->register traffic of the main loop is inline asm with hand-counted s_waitcnt vmcnt(N)
 //    (hipcc drains the queue at every use otherwise, see conv_igemm.hip).
 #include "cs_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <utility>
 
@@ -37,7 +38,6 @@ struct C2Params {
     unsigned char* bits_out;       // nullable: one bit per stored element (> 0)
     const unsigned char* bits_in;  // nullable: one bit per destination element, 0 -> the element is stored as 0
     float* slab;                   // nullable: per-workgroup partial column sums [rows][2][NOUT]
-    int want_sq;                   // slab also gets sums of squares
     int act;                       // CS_ACT_NONE / CS_ACT_RELU
     int SH, SW, SC, NS;
     int DH, DW, NOUT;
@@ -50,6 +50,9 @@ struct C2Params {
     unsigned src_bytes;
     unsigned pix_bytes;            // SC * 2
     unsigned wpk_bytes;            // whole packed weight tensor (the range check of a raw buffer covers voffset + soffset)
+#ifdef CS_DEBUG_V2
+    unsigned long long* dbg;       // diagnostic build only: s_memtime stamps [workgroup][wave][6]
+#endif
 };
 
 // n / d for n < 2^31, d >= 2: q = umulhi(n, mg) >> sh with mg = floor(2^(31+l) / d) + 1, sh = l - 1, l = ceil(log2 d)
@@ -227,22 +230,50 @@ __device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
 }
 
 // ---- epilogue of one wave: TM pixel tiles (32 pixels each, pixel on the lane) x 32 channels (on the register index) ----
-// acc[i][r]: pixel m0w + 32*i + (lane & 31), channel n_w + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+// accumulator tile i, register r: pixel m0w + 32*i + (lane & 31), channel n_w + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+// Its global operands are fetched BEFORE the main loop (EpiOps): stamped, the epilogue spent ~2/3 of its 5-7 k cycles waiting
+// for the shift vector and for one residual / mask load per tile, each a full memory latency with nothing else in flight.
+template <int TM> struct EpiOps {
+    float sh[16];
+    uint4 ra[TM], rb[TM];      // residual / add: the lane's two 16-byte pieces per tile, in STORED arrangement
+    unsigned mb[TM];           // mask bits of the wave's 32 channels per tile
+};
+
 template <int TM>
-__device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int n_w, unsigned slab_row) {
+__device__ __forceinline__ void epi_prefetch(const C2Params& p, unsigned m0w, int n_w, EpiOps<TM>& e) {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, hh = lane >> 5;
-    float sh[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.shift) s = *reinterpret_cast<const float4*>(p.shift + n_w + 8 * g + 4 * hh);
-        sh[4 * g] = s.x; sh[4 * g + 1] = s.y; sh[4 * g + 2] = s.z; sh[4 * g + 3] = s.w;
+        e.sh[4 * g] = s.x; e.sh[4 * g + 1] = s.y; e.sh[4 * g + 2] = s.z; e.sh[4 * g + 3] = s.w;
     }
-    float s1[16], s2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.residual);
+    const unsigned cofs = hh ? 8u : 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const unsigned m = m0w + 32u * i + (unsigned)l31;
+        const bool ok = m < p.M;
+        const size_t eoff = (size_t)m * (unsigned)p.NOUT + (unsigned)n_w;
+        e.ra[i] = make_uint4(0, 0, 0, 0);
+        e.rb[i] = make_uint4(0, 0, 0, 0);
+        e.mb[i] = 0u;
+        if (res && ok) {
+            e.ra[i] = *reinterpret_cast<const uint4*>(res + eoff + cofs);
+            e.rb[i] = *reinterpret_cast<const uint4*>(res + eoff + 16 + cofs);
+        }
+        if (p.bits_in && ok) e.mb[i] = reinterpret_cast<const unsigned*>(p.bits_in)[eoff >> 5];
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int n_w, unsigned slab_row, EpiOps<TM>& e) {
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float s1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
     bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(p.dst);
     const unsigned cofs = hh ? 8u : 0u;
     auto tile = [&]<int I>() {
@@ -259,13 +290,9 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
 #endif
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[r] + sh[r];
-        if (res) {
-            uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                ra = *reinterpret_cast<const uint4*>(res + eoff + cofs);
-                rb = *reinterpret_cast<const uint4*>(res + eoff + 16 + cofs);
-            }
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + e.sh[r];
+        if (p.residual) {
+            uint4 ra = e.ra[i], rb = e.rb[i];
             // stored arrangement -> accumulator arrangement (the swap is an involution)
             swap32(ra.x, ra.z); swap32(ra.y, ra.w);
             swap32(rb.x, rb.z); swap32(rb.y, rb.w);
@@ -283,8 +310,7 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
             for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
         if (p.bits_in) {
-            const unsigned mb = ok ? reinterpret_cast<const unsigned*>(p.bits_in)[eoff >> 5] : 0u;
-            const unsigned mine = mb >> (4 * hh);
+            const unsigned mine = e.mb[i] >> (4 * hh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = ((mine >> (8 * (r >> 2) + (r & 3))) & 1u) ? v[r] : 0.f;
         }
@@ -297,7 +323,6 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
                 float lo, hi;
                 unpack2(pk[k], lo, hi);            // statistics are those of the STORED values
                 s1[2 * k] += lo; s1[2 * k + 1] += hi;
-                s2[2 * k] += lo * lo; s2[2 * k + 1] += hi * hi;
             }
         }
         // groups (0,1) and (2,3): after the swaps lanes 0-31 hold channels 16j .. 16j+7, lanes 32-63 channels 16j+8 .. 16j+15
@@ -318,23 +343,18 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
     };
     [&]<int... Is>(std::integer_sequence<int, Is...>) { (tile.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TM>{});
     if (p.slab) {
-        // fold the 32 pixels-lanes of each half; lane (l31 == r) keeps channel register r
-        float mine1 = 0.f, mine2 = 0.f;
+        // fold the 32 pixel-lanes of each half; lane (l31 == r) keeps channel register r
+        float mine1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float a = s1[r], b = s2[r];
+            float a = s1[r];
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
-                a += __shfl_xor(a, off, 64);
-                if (p.want_sq) b += __shfl_xor(b, off, 64);
-            }
-            if (l31 == r) { mine1 = a; mine2 = b; }
+            for (int off = 16; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (l31 == r) mine1 = a;
         }
         if (l31 < 16) {
             const int ch = n_w + 8 * (l31 >> 2) + 4 * hh + (l31 & 3);
-            float* row = p.slab + (size_t)slab_row * 2 * p.NOUT;
-            row[ch] = mine1;
-            row[p.NOUT + ch] = mine2;
+            p.slab[(size_t)slab_row * 2 * p.NOUT + ch] = mine1;
         }
     }
 }
@@ -354,6 +374,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hh = lane >> 5;
+#ifdef CS_DEBUG_V2
+    unsigned long long t_stamp[6];
+#define CS_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_stamp[i]))
+    CS_STAMP(0);
+#else
+#define CS_STAMP(i)
+#endif
 
     // XCD-aware tile order: id = 8*slot + xcd, all N tiles of one M tile back to back on one XCD (conv_igemm.hip)
     const unsigned bid = blockIdx.x;
@@ -401,6 +428,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     const unsigned smem_base = lds_off(smem);
 
     static_assert(TM == 4, "the register map of the main loop is laid out for 4 pixel tiles per wave");
+    EpiOps<TM> eops;
+    if (alive) epi_prefetch<TM>(p, m0w, n_w, eops);
+    CS_STAMP(4);
     own_registers();
     vzero_seq(std::make_integer_sequence<int, 64>{});
     const unsigned hhb = (unsigned)hh * 256u;
@@ -413,6 +443,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     bload4<1>(rsrc_b, bvoff, wsoff); wsoff += 4096u;
     wait_vm<8>();
     raw_barrier();
+    CS_STAMP(1);
 
     unsigned nxt_soff = 128u;                    // channel offset (bytes) of the chunk being fetched
 
@@ -457,8 +488,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     }
     // MFMA results -> VALU readers: the hazard padding hipcc would insert for its own MFMAs
     asm volatile("s_nop 15\n\ts_nop 15");
+    CS_STAMP(2);
     if (!alive) return;
-    epilogue_t<TM>(p, m0w, n_w, mtile * WM + wm);
+    epilogue_t<TM>(p, m0w, n_w, mtile * WM + wm, eops);
+#ifdef CS_DEBUG_V2
+    CS_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)");
+    CS_STAMP(5);
+    if (p.dbg && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
+        o[0] = t_stamp[0]; o[1] = t_stamp[4]; o[2] = t_stamp[1]; o[3] = t_stamp[2]; o[4] = t_stamp[3]; o[5] = t_stamp[5];
+    }
+#endif
 }
 
 // ---- weights [ROWS][taps][COLS] bf16 (ROWS = destination channels, COLS = contraction channels, both staged layouts of
@@ -570,6 +611,9 @@ int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
             raised = true;
         }
     }
+    char name[64];
+    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,4,1,4,%d>", NBW);
+    cs_set_variant_(name);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
@@ -580,6 +624,7 @@ int launch_halo(const C2Plan& pl, hipStream_t st) {
     if (pl.cfg == 2) {
         const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 256);
         dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
+        cs_set_variant_("conv2_halo_kernel<9,3,4,2,2,8>");
         hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8>), grid, dim3(256), 8 * 8192, st, p);
         CS_LAUNCH_CHECK();
         return CS_OK;
@@ -593,7 +638,15 @@ int launch_halo(const C2Plan& pl, hipStream_t st) {
     }
 }
 
+#ifdef CS_DEBUG_V2
+unsigned long long* g_dbg_buf = nullptr;
+#endif
+
 }  // namespace
+
+#ifdef CS_DEBUG_V2
+extern "C" int cs_debug_set_stamp_buffer(void* p) { g_dbg_buf = reinterpret_cast<unsigned long long*>(p); return CS_OK; }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int cs_conv2d_packed_supported(const CsConvGeom* g, int dgrad) {
@@ -641,6 +694,9 @@ extern "C" int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const vo
     pl.p.src = x; pl.p.wpk = w_packed; pl.p.dst = y;
     pl.p.shift = shift; pl.p.residual = residual; pl.p.act = act;
     pl.p.bits_out = positive_bits;
+#ifdef CS_DEBUG_V2
+    pl.p.dbg = g_dbg_buf;
+#endif
     return launch_halo(pl, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -656,5 +712,8 @@ extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const
     pl.p.residual = add; pl.p.act = CS_ACT_NONE;
     pl.p.bits_in = mask_bits;
     pl.p.slab = partial_rows;
+#ifdef CS_DEBUG_V2
+    pl.p.dbg = g_dbg_buf;
+#endif
     return launch_halo(pl, reinterpret_cast<hipStream_t>(stream));
 }

@@ -108,6 +108,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- host side error plumbing (cs_api.cpp owns the storage) ----
 extern "C" void cs_set_error_(const char* msg);
+extern "C" void cs_set_variant_(const char* name);
 #define CS_CHECK_ARG(cond, msg)                         \
     do {                                                \
         if (!(cond)) {                                  \

@@ -177,16 +177,28 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
     for (long long idx = (long long)b * blockDim.x + threadIdx.x; idx < t1 + t2; idx += (long long)nb * blockDim.x) {
         int k, c, rs;
         const bool first = idx < t1;
-        if (first) {
-            c = (int)(idx % d.Cp); rs = (int)((idx / d.Cp) % RS); k = (int)(idx / ((long long)d.Cp * RS));
+        const long long j = first ? idx : idx - t1;
+        if (first ? d.fwd_packed : d.bwd_packed) {
+            // MFMA-fragment order of csrc/conv_v2.hip: [32-row tile][64-column chunk][tap][16-deep step][lane][8]; rows = destination
+            // channels (k forward, c data gradient), columns = contraction channels; the data-gradient form mirrors the taps
+            const int e = (int)(j & 7), lane = (int)((j >> 3) & 63), k16 = (int)((j >> 9) & 3);
+            long long u = j >> 11;
+            const int t = (int)(u % RS); u /= RS;
+            const int ncc = (first ? d.Cp : d.Kp) / 64;
+            const int cc = (int)(u % ncc);
+            const int rt = (int)(u / ncc);
+            const int row = rt * 32 + (lane & 31), col = cc * 64 + k16 * 16 + 8 * (lane >> 5) + e;
+            if (first) { k = row; c = col; rs = t; }
+            else { c = row; k = col; rs = RS - 1 - t; }
+        } else if (first) {
+            c = (int)(j % d.Cp); rs = (int)((j / d.Cp) % RS); k = (int)(j / ((long long)d.Cp * RS));
         } else {
-            const long long j = idx - t1;
             k = (int)(j % d.Kp); rs = (int)((j / d.Kp) % RS); c = (int)(j / ((long long)d.Kp * RS));
         }
         float v = 0.f;
         if (k < d.K && c < d.Cin) v = d.w[((long long)k * d.Cin + c) * RS + rs] * ((d.gamma ? d.gamma[k] : 1.f) * (1.0f / sqrtf(d.var[k] + d.eps)));
-        if (first) w_khwc[idx] = from_f32<T>(v);
-        else w_chwk[idx - t1] = from_f32<T>(v);
+        if (first) w_khwc[j] = from_f32<T>(v);
+        else w_chwk[j] = from_f32<T>(v);
     }
 }
 

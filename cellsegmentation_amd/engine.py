@@ -176,14 +176,33 @@ def _bn_uses_batch_stats(bn, bn_train):
     return bn is not None and bn_train and bn.training
 
 
-def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded, training):
+def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits):
+    """(forward operand packed?, data-gradient operand packed?) for the packed-operand kernels of csrc/conv_v2.hip.
+    The data gradient only qualifies when its ReLU mask (if it applies one) exists as a bit tensor."""
+    if not PACKED or batch_stats or u.grouped or u.act not in (ACT_NONE, ACT_RELU):
+        return False, False
+    pkf = K.packed_supported(geom, dtype, dgrad=False)
+    pkb = bool(need_bwd) and K.packed_supported(geom, dtype, dgrad=True) and (u.src not in plan.relu_slots or u.src in bits)
+    return pkf, pkb
+
+
+_STAGE_EPOCH = [0]
+
+
+def invalidate_staged():
+    """Drop every cached staged-weight set (of every plan).  Needed whenever parameters or BN buffers change behind the
+    host's back: a HIP-graph replay of a training step updates them without running any Python (graphed.GraphedStep)."""
+    _STAGE_EPOCH[0] += 1
+
+
+def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded, training, geom=None, pkf=False, pkb=False):
     """BN folding + weight staging.  Cached only for frozen parameters and for no-grad passes: a forward that will
     be followed by an optimizer step (`training` and the parameter requires grad) always stages afresh and leaves the
     cache invalid, because tensor version counters cannot be trusted to see the update -- torch's fused optimizers
     (`Adam(fused=True)`) write the parameters without bumping `_version`."""
     conv, bn = u.conv, u.bn
     key_t = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-    key = (dtype, Cp, Kp, need_bwd, folded) + tuple((t._version, t.data_ptr()) if t is not None else None for t in key_t)
+    key = (_STAGE_EPOCH[0], dtype, Cp, Kp, need_bwd, folded, pkf, pkb) + tuple((t._version, t.data_ptr()) if t is not None else None for t in key_t)
     if training and any(t is not None and t.requires_grad for t in key_t):
         key = None
     elif u._cache is not None and u._cache[0] == key:
@@ -194,7 +213,7 @@ def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded, training):
     if folded and bn is not None and not u.grouped:
         w_khwc, w_chwk, scale, shift, rstd = K.stage_conv_bn(w, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                              bn.eps, bias, dtype, Cp, Kp, want_bwd=need_bwd)
-        staged = SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd)
+        staged = _packed(SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd), geom, pkf, pkb)
         u._cache = (key, staged)
         return staged
     if folded and bn is not None:
@@ -205,9 +224,20 @@ def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded, training):
         w_khwc, w_chwk = K.weight_prep_grouped(w, scale, dtype, want_fwd=True, want_bwd=need_bwd)
     else:
         w_khwc, w_chwk = K.weight_prep(w, scale, dtype, Cp, Kp, want_fwd=True, want_bwd=need_bwd)
-    staged = SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=_pad_vec(shift, Kp), rstd=rstd)
+    staged = _packed(SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=_pad_vec(shift, Kp), rstd=rstd), geom, pkf, pkb)
     u._cache = (key, staged)
     return staged
+
+
+def _packed(st, geom, pkf, pkb):
+    """Layer-by-layer staging path: re-order the plain operands for the packed-operand kernels (the one-launch StagePack
+    writes that order directly)."""
+    st.fwd_packed, st.bwd_packed = bool(pkf), bool(pkb and st.w_chwk is not None)
+    if st.fwd_packed:
+        st.w_khwc = K.pack_conv_weights(geom, st.w_khwc, dgrad=False)
+    if st.bwd_packed:
+        st.w_chwk = K.pack_conv_weights(geom, st.w_chwk, dgrad=True)
+    return st
 
 
 def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
@@ -269,15 +299,22 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             need_bwd = save and requires.get(u.src, False)
             batch_stats = _bn_uses_batch_stats(u.bn, bn_train)
             pre = prestaged.get(ui)
-            if pre is not None and pre[0] == (Cp, Kp, need_bwd) and not batch_stats:
+            pkf, pkb = _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits)
+            # A pass that will be followed by an optimizer step, or that updates BN running statistics in place, must not leave
+            # a version-keyed cache behind: fused optimizers and our own kernels write those tensors without bumping `_version`
+            # (a later no-grad pass would be served the old weights; the one-launch pack path below never touches `_cache`)
+            if (save and any(p_ is not None and p_.requires_grad for p_ in (conv.weight, conv.bias) + ((u.bn.weight, u.bn.bias) if u.bn is not None else ()))) \
+                    or batch_stats:
+                u._cache = None
+            if pre is not None and pre[0] == (Cp, Kp, need_bwd, pkf, pkb) and not batch_stats:
                 st = pre[1]
             else:
                 if pre is not None:
-                    packs.pop(dtype, None)          # the layout changed (other requires_grad pattern): rebuild next time
-                st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save)
+                    packs.pop(dtype, None)          # the layout changed (other requires_grad pattern / geometry): rebuild next time
+                st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save, geom=geom, pkf=pkf, pkb=pkb)
                 if (record is not None and not batch_stats and u.bn is not None and not u.grouped
                         and any(p_ is not None and p_.requires_grad for p_ in (conv.weight, conv.bias, u.bn.weight, u.bn.bias))):
-                    record.append((ui, conv, u.bn, Cp, Kp, need_bwd))
+                    record.append((ui, conv, u.bn, Cp, Kp, need_bwd, pkf, pkb))
             # the stem runs on a pixel-paired image (kernels.stem_*): 28 instead of 49 K chunks
             stem = STEM_PAIRED and K.is_stem_geom(geom) and not u.grouped and res is None and conv.in_channels <= 3
             xp = K.stem_pair_input(x) if stem else None
@@ -285,6 +322,11 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             if not batch_stats:
                 if stem:
                     y = K.stem_fwd(geom, xp, wp, None, st.shift, u.act)
+                elif getattr(st, "fwd_packed", False):
+                    if save and RELU_BITS and u.act == ACT_RELU:
+                        y, bits[u.dst] = K.conv_fwd_packed(geom, x, st.w_khwc, st.shift, res, u.act, want_bits=True)
+                    else:
+                        y = K.conv_fwd_packed(geom, x, st.w_khwc, st.shift, res, u.act)
                 elif save and RELU_BITS and u.act == ACT_RELU and Kp % 32 == 0:
                     # one bit per output next to the ReLU output: the data gradient that later masks with this tensor reads
                     # 1 byte per 16 (the bf16 masks are ~1/8 of a training step's HBM traffic)
@@ -365,10 +407,11 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
     if bumped:
         torch._foreach_add_(bumped, 1)
     if record:
-        pk = K.StagePack([(conv_, bn_, cp_, kp_, nb_) for _, conv_, bn_, cp_, kp_, nb_ in record], dtype)
+        pk = K.StagePack([r_[1:] for r_ in record], dtype)
         pk.by_unit = {}
-        for (ui_, _, _, cp_, kp_, nb_), (w_khwc, w_chwk, scale, shift, rstd) in zip(record, pk.staged):
-            pk.by_unit[ui_] = ((cp_, kp_, nb_), SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd))
+        for (ui_, _, _, cp_, kp_, nb_, pkf_, pkb_), (w_khwc, w_chwk, scale, shift, rstd) in zip(record, pk.staged):
+            pk.by_unit[ui_] = ((cp_, kp_, nb_, pkf_, pkb_), SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd,
+                                                                             fwd_packed=bool(pkf_), bwd_packed=bool(pkb_ and nb_)))
         packs[dtype] = pk
     return SimpleNamespace(t=t, aux=aux, in_hw=in_hw, bits=bits)
 
@@ -397,6 +440,7 @@ def _defers(u, a, need, ui):
             and not a.train and not u.grouped and u.bn is not None and u.conv.bias is None)
 
 
+PACKED = os.environ.get("CELLSEG_PACKED", "1") != "0"                # packed-operand conv kernels (0: first-generation igemm everywhere)
 RELU_BITS = os.environ.get("CELLSEG_RELU_BITS", "1") != "0"          # bit masks next to ReLU outputs (0: bf16 tensors as masks)
 STEM_PAIRED = os.environ.get("CELLSEG_STEM_PAIRED", "1") != "0"      # pixel-paired stem (0: the generic 7x7 path, for A/B runs)
 _grad_sink = None
@@ -625,7 +669,14 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 mbits = state.bits.get(u.src) if mask is not None else None
                 if mbits is not None:
                     mask = None
-                if final:
+                if getattr(a.st, "bwd_packed", False):
+                    if mask is not None:
+                        raise RuntimeError(f"{u.name}: packed data-gradient operand staged but the ReLU mask is not a bit tensor")
+                    if final:
+                        dx, gsum_cache[u.src] = K.conv_dgrad_packed(geom, dz, a.st.w_chwk, add=pending, mask_bits=mbits, want_colsum=True)
+                    else:
+                        dx = K.conv_dgrad_packed(geom, dz, a.st.w_chwk, add=pending, mask_bits=mbits)
+                elif final:
                     # column sums of the finished gradient feed its producer's BN/bias gradients: left as per-workgroup partial
                     # rows where the launch allows it (the batched finalize folds them; one small launch less per layer)
                     cs = take((geom.C,)) if (geom.stride != 1 or u.grouped) else None

@@ -12,6 +12,8 @@ running statistics and optimizer state are updated in place by the replay exactl
 """
 import torch
 
+from . import engine
+
 
 class GraphedStep:
     """``step = GraphedStep(step_fn, (x, y, ...))`` then ``loss = step(x, y, ...)`` per batch.
@@ -45,4 +47,6 @@ class GraphedStep:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replay updated parameters / BN statistics without running host code: cached staged weights are stale now
+        engine.invalidate_staged()
         return self.outputs

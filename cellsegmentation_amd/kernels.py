@@ -94,8 +94,9 @@ def stage_conv_bn(w, gamma, beta, mean, var, eps, conv_bias, dtype, Cp, Kp, want
 class StagePack:
     """Every eval-mode Conv2d+BatchNorm2d of a network staged by ONE launch (cs_stage_conv_bn_multi).
 
-    layers: [(conv, bn, Cp, Kp, want_bwd)].  The staging buffers and the device descriptor table are allocated once and
-    rewritten by every launch(); valid() tells whether the parameter tensors are still the ones the table points at."""
+    layers: [(conv, bn, Cp, Kp, want_bwd, fwd_packed, bwd_packed)].  The staging buffers and the device descriptor table are
+    allocated once and rewritten by every launch(); valid() tells whether the parameter tensors are still the ones the table
+    points at.  *_packed: the operand is written in the MFMA-fragment order of the packed-operand kernels (conv_v2.hip)."""
 
     def __init__(self, layers, dtype):
         lib = _lib.load()
@@ -103,7 +104,7 @@ class StagePack:
         self.dtype, self.layers, self.staged = dtype, layers, []
         arr = (_lib.CsStageDesc * len(layers))()
         block = 0
-        for i, (conv, bn, Cp, Kp, want_bwd) in enumerate(layers):
+        for i, (conv, bn, Cp, Kp, want_bwd, pkf, pkb) in enumerate(layers):
             K_, Cin, R, S = conv.weight.shape
             w_khwc = torch.empty((Kp, R, S, Cp), dtype=dtype, device=dev)
             w_chwk = torch.empty((Cp, R, S, Kp), dtype=dtype, device=dev) if want_bwd else None
@@ -116,6 +117,9 @@ class StagePack:
             d.scale, d.shift, d.rstd = vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr()
             d.eps = float(bn.eps)
             d.K, d.Cin, d.R, d.S, d.Cp, d.Kp, d.block0 = K_, Cin, R, S, Cp, Kp, block
+            d.fwd_packed, d.bwd_packed = int(bool(pkf)), int(bool(pkb and want_bwd))
+            if (pkf and (Kp % 32 or Cp % 64)) or (pkb and want_bwd and (Cp % 32 or Kp % 64)):
+                raise ValueError("StagePack: packed layouts need 32-row tiles and 64-channel chunks")
             nb = lib.cs_stage_conv_bn_blocks(K_, Cin, R, S, Cp, Kp, 1, 1 if want_bwd else 0)
             if nb < 1:
                 raise ValueError("StagePack: bad layer extents")
@@ -127,7 +131,7 @@ class StagePack:
 
     def _key(self):
         out = []
-        for conv, bn, _, _, _ in self.layers:
+        for conv, bn, *_ in self.layers:
             for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var):
                 out.append(t.data_ptr() if t is not None else 0)
         return tuple(out)
@@ -186,6 +190,7 @@ def _timed(kind, geom, dtype, fn, extra_tensors=0, batch=1):
     g = {f: getattr(geom, f) for f, _ in geom._fields_}
     g["extra"] = extra_tensors
     g["batch"] = batch
+    g["variant"] = (_lib.load().cs_last_conv_variant() or b"").decode()      # what the library actually launched
     _timer.records.append((kind, g, dtype, s, e))
     return rc
 

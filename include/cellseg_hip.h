@@ -32,6 +32,10 @@ enum { CS_ACT_NONE = 0, CS_ACT_RELU = 1, CS_ACT_SILU = 2, CS_ACT_SIGMOID = 3 };
 
 int cs_abi_version(void);
 const char* cs_last_error(void);
+/* Name of the convolution-family kernel instantiation the calling thread launched last, e.g. "igemm_dma_kernel<bf16,64,128,1,false,true>",
+ * "conv2_halo_kernel<9,3,4,1,4,4>", "wgrad_dma_kernel<128,3,true,32>": the names rocprofv3 reports (template arguments without spaces),
+ * so that bench.py's roofline entries can be checked against profiles/ (tools/check_bench_vs_profile.py). */
+const char* cs_last_conv_variant(void);
 
 /* Geometry of one 2-D convolution (torch.nn.Conv2d as used at model/resnet.py:20,23,51,53,55,
  * 111,183,198,164).  Input N x H x W x C (C = stored/padded channels), output N x P x Q x K. */
@@ -106,6 +110,10 @@ typedef struct CsStageDesc {
     float eps;
     int32_t K, Cin, R, S, Cp, Kp;
     int32_t block0;
+    /* nonzero: write that operand in the MFMA-fragment order cs_conv2d_fwd_packed / cs_conv2d_dgrad_packed read (what
+     * cs_pack_conv_weights produces from the plain layout; needs Kp % 32 == 0 and Cp % 64 == 0 for fwd, Cp % 32 == 0 and
+     * Kp % 64 == 0 for bwd) instead of w_khwc / w_chwk order; the buffer sizes are the same */
+    int32_t fwd_packed, bwd_packed;
 } CsStageDesc;
 int cs_stage_conv_bn_blocks(int K, int Cin, int R, int S, int Cp, int Kp, int want_fwd, int want_bwd);
 int cs_stage_conv_bn_multi(const CsStageDesc* desc, int n, int total_blocks, int dtype, void* stream);

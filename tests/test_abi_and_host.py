@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/cellseg_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == declared, "ctypes signature table out of sync with the header"
-    assert lib.cs_abi_version() >= 2
+    assert lib.cs_abi_version() >= 3
 
 
 def test_argument_checks_without_gpu():

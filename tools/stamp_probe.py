@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic build only (make -C cellsegmentation_amd/csrc DEBUG=1): per-phase s_memtime shares of the packed 3x3 kernel.
+   python tools/stamp_probe.py [shape ...]     (shapes of tools/conv_microbench.py)"""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cellsegmentation_amd import kernels as K, _lib
+from conv_microbench import SHAPES
+
+lib = ctypes.CDLL(_lib.LIB_PATH)
+dev = torch.device("cuda:0")
+for name in sys.argv[1:] or ["l1_3x3", "l2_3x3", "l3_3x3", "l4_3x3"]:
+    N, H, W, C, Kc, R, s, p = SHAPES[name]
+    g = K.make_geom(N, H, W, C, Kc, R, R, s, p)
+    x = torch.randn((N, H, W, C), device=dev).to(torch.bfloat16)
+    w = torch.randn((Kc, C, R, R), device=dev) / (C * R * R) ** 0.5
+    wk, wc = K.weight_prep(w, None, torch.bfloat16, C, Kc, True, True)
+    wp = K.pack_conv_weights(g, wk, False)
+    shift = torch.zeros((Kc,), device=dev)
+    nblk = 8 * ((N * H * W + 127) // 128 + 8) * max(1, Kc // 64)
+    buf = torch.zeros((nblk, 4, 6), dtype=torch.int64, device=dev)
+    for _ in range(3):
+        K.conv_fwd_packed(g, x, wp, shift, None, K.CS_ACT_RELU, want_bits=True)
+    torch.cuda.synchronize()
+    lib.cs_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    K.conv_fwd_packed(g, x, wp, shift, None, K.CS_ACT_RELU, want_bits=True)
+    torch.cuda.synchronize()
+    lib.cs_debug_set_stamp_buffer(None)
+    b = buf.cpu().reshape(-1, 6)
+    b = b[b[:, 0] != 0].double()
+    d = [b[:, i + 1] - b[:, i] for i in range(5)]
+    ncc = C // 64
+    ideal = ncc * 9 * 16 * 32
+    names = ["index math", "first loads + barrier", "main loop", "epilogue issue", "store drain"]
+    print(f"{name}: waves {len(b)}, main loop alone = {ideal} MFMA cycles; total med {(b[:, 5] - b[:, 0]).median():.0f}")
+    for n_, v in zip(names, d):
+        print(f"    {n_:24s} med {v.median():8.0f}   p10 {v.quantile(0.1):8.0f}   p90 {v.quantile(0.9):8.0f}")
