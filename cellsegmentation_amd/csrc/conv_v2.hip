@@ -128,6 +128,16 @@ template <int ACC, int B, int A> __device__ __forceinline__ void mfma() {
     asm volatile("v_mfma_f32_32x32x16_bf16 v[%c0:%c1], v[%c2:%c3], v[%c4:%c5], v[%c0:%c1]" ::"i"(ACC), "i"(ACC + 15), "i"(B), "i"(B + 3), "i"(A),
                  "i"(A + 3));
 }
+// the LAST MFMA of an accumulator tile writes a compiler value instead of the owned registers: the epilogue of tile i then runs
+// while the MFMAs of tiles i+1.. are still executing, with 16 instead of 64 result registers live and no copy-out.  hipcc does
+// not know this statement is an MFMA: the result -> VALU wait states are inside the string.
+template <int ACC, int B, int A> __device__ __forceinline__ f32x16 mfma_out() {
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, v[%c1:%c2], v[%c3:%c4], v[%c5:%c6]\n\ts_nop 15\n\ts_nop 3"
+                 : "=v"(d)
+                 : "i"(B), "i"(B + 3), "i"(A), "i"(A + 3), "i"(ACC), "i"(ACC + 15));
+    return d;
+}
 // operand-row addresses of one tap for the 4 pixel tiles -> address set S (see row_addr; hhb = chunk-column bit of the lane half)
 template <int S>
 __device__ __forceinline__ void addr4(unsigned q0, unsigned q1, unsigned q2, unsigned q3, unsigned sh, unsigned hhb, unsigned cf0) {
@@ -154,49 +164,55 @@ template <int BASE, int... Rs> __device__ __forceinline__ void dbg_tile(f32x16& 
     ((out[Rs] = vget<BASE + Rs>()), ...);
 }
 
-// One tap-step of the 4 x (32 px x 32 ch) wave tile: 16 MFMA, 16 ds_read_b128, software-pipelined over the two fragment sets
-// (set 0: 16-deep steps 0 and 2, set 1: steps 1 and 3).  KIND 0 = first tap of a chunk (cold start: own addresses + first
-// reads), 1 = middle (entered with its first 8 reads in flight, leaves with the next tap's in flight), 2 = last tap of a chunk
-// (no read-ahead: the next chunk's stage is only visible after the barrier).  Every MFMA waits for exactly its own fragment:
-// 7 younger reads outstanding in steady state.
-template <int CUR, int S, unsigned STG, int KIND>
+// One tap-step of a TM x (32 px x 32 ch) wave tile: 4*TM MFMA and 4*TM ds_read_b128, software-pipelined over the two fragment
+// sets (set 0: 16-deep steps 0 and 2, set 1: steps 1 and 3).  COLD = first tap after a barrier (own addresses + first reads);
+// otherwise the tap is entered with its first 2*TM reads in flight.  AHEAD = leave with the next tap's first reads in flight
+// (addresses from sh_next unless SAME, stage offset NSTG); the last tap before a barrier has no read-ahead (the next stage is
+// only visible after the barrier).  Every MFMA waits for exactly its own fragment: 2*TM - 1 younger reads in steady state.
+template <int TM, int I, int... Is> struct TileLoop {
+    template <typename F> static __device__ __forceinline__ void run(F&& f) {
+        f.template operator()<I>();
+        if constexpr (sizeof...(Is) > 0) TileLoop<TM, Is...>::run(f);
+    }
+};
+template <int TM, typename F> __device__ __forceinline__ void for_tiles(F&& f) {
+    if constexpr (TM == 2) TileLoop<2, 0, 1>::run(f);
+    else if constexpr (TM == 3) TileLoop<3, 0, 1, 2>::run(f);
+    else TileLoop<4, 0, 1, 2, 3>::run(f);
+}
+
+struct NoTile { template <int I> __device__ __forceinline__ void operator()(const f32x16&) const {} };
+
+template <int TM, int CUR, int S, unsigned STG, unsigned NSTG, bool COLD, bool AHEAD, bool SAME, bool FINAL = false, typename OnTile = NoTile>
 __device__ __forceinline__ void tap_mfma(unsigned q0, unsigned q1, unsigned q2, unsigned q3, unsigned sh_cur, unsigned sh_next, unsigned hhb,
-                                         unsigned cf0) {
-    constexpr int A = R_AD + 4 * S, N = R_AD + 4 * (1 - S);
+                                         unsigned cf0, OnTile&& on_tile = NoTile{}) {
+    constexpr int A = R_AD + 4 * S, N = SAME ? A : R_AD + 4 * (1 - S);
     constexpr int F0 = R_AF, F1 = R_AF + 16;
     constexpr int B = R_B + 16 * CUR;
-    if constexpr (KIND == 0) {
+    constexpr int W = 2 * TM - 1;
+    static_assert(!(FINAL && AHEAD), "the final tap of a workgroup reads nothing ahead");
+    if constexpr (COLD) {
         addr4<S>(q0, q1, q2, q3, sh_cur, hhb, cf0);
-        lds_rd<F0 + 0, A + 0, STG>(); lds_rd<F0 + 4, A + 1, STG>(); lds_rd<F0 + 8, A + 2, STG>(); lds_rd<F0 + 12, A + 3, STG>();
-        lds_rd<F1 + 0, A + 0, STG + 512>(); lds_rd<F1 + 4, A + 1, STG + 512>(); lds_rd<F1 + 8, A + 2, STG + 512>(); lds_rd<F1 + 12, A + 3, STG + 512>();
+        for_tiles<TM>([&]<int i>() { lds_rd<F0 + 4 * i, A + i, STG>(); });
+        for_tiles<TM>([&]<int i>() { lds_rd<F1 + 4 * i, A + i, STG + 512>(); });
     }
-    if constexpr (KIND != 2) addr4<1 - S>(q0, q1, q2, q3, sh_next, hhb, cf0);
-    wait_lgkm<7>(); mfma<R_ACC + 0, B + 0, F0 + 0>(); lds_rd<F0 + 0, A + 0, STG + 1024>();
-    wait_lgkm<7>(); mfma<R_ACC + 16, B + 0, F0 + 4>(); lds_rd<F0 + 4, A + 1, STG + 1024>();
-    wait_lgkm<7>(); mfma<R_ACC + 32, B + 0, F0 + 8>(); lds_rd<F0 + 8, A + 2, STG + 1024>();
-    wait_lgkm<7>(); mfma<R_ACC + 48, B + 0, F0 + 12>(); lds_rd<F0 + 12, A + 3, STG + 1024>();
-    wait_lgkm<7>(); mfma<R_ACC + 0, B + 4, F1 + 0>(); lds_rd<F1 + 0, A + 0, STG + 1536>();
-    wait_lgkm<7>(); mfma<R_ACC + 16, B + 4, F1 + 4>(); lds_rd<F1 + 4, A + 1, STG + 1536>();
-    wait_lgkm<7>(); mfma<R_ACC + 32, B + 4, F1 + 8>(); lds_rd<F1 + 8, A + 2, STG + 1536>();
-    wait_lgkm<7>(); mfma<R_ACC + 48, B + 4, F1 + 12>(); lds_rd<F1 + 12, A + 3, STG + 1536>();
-    if constexpr (KIND != 2) {
-        wait_lgkm<7>(); mfma<R_ACC + 0, B + 8, F0 + 0>(); lds_rd<F0 + 0, N + 0, STG>();
-        wait_lgkm<7>(); mfma<R_ACC + 16, B + 8, F0 + 4>(); lds_rd<F0 + 4, N + 1, STG>();
-        wait_lgkm<7>(); mfma<R_ACC + 32, B + 8, F0 + 8>(); lds_rd<F0 + 8, N + 2, STG>();
-        wait_lgkm<7>(); mfma<R_ACC + 48, B + 8, F0 + 12>(); lds_rd<F0 + 12, N + 3, STG>();
-        wait_lgkm<7>(); mfma<R_ACC + 0, B + 12, F1 + 0>(); lds_rd<F1 + 0, N + 0, STG + 512>();
-        wait_lgkm<7>(); mfma<R_ACC + 16, B + 12, F1 + 4>(); lds_rd<F1 + 4, N + 1, STG + 512>();
-        wait_lgkm<7>(); mfma<R_ACC + 32, B + 12, F1 + 8>(); lds_rd<F1 + 8, N + 2, STG + 512>();
-        wait_lgkm<7>(); mfma<R_ACC + 48, B + 12, F1 + 12>(); lds_rd<F1 + 12, N + 3, STG + 512>();
+    if constexpr (AHEAD && !SAME) addr4<1 - S>(q0, q1, q2, q3, sh_next, hhb, cf0);
+    for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 0, F0 + 4 * i>(); lds_rd<F0 + 4 * i, A + i, STG + 1024>(); });
+    for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 4, F1 + 4 * i>(); lds_rd<F1 + 4 * i, A + i, STG + 1536>(); });
+    if constexpr (AHEAD) {
+        for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 8, F0 + 4 * i>(); lds_rd<F0 + 4 * i, N + i, NSTG>(); });
+        for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 12, F1 + 4 * i>(); lds_rd<F1 + 4 * i, N + i, NSTG + 512>(); });
     } else {
-        wait_lgkm<7>(); mfma<R_ACC + 0, B + 8, F0 + 0>();
-        wait_lgkm<6>(); mfma<R_ACC + 16, B + 8, F0 + 4>();
-        wait_lgkm<5>(); mfma<R_ACC + 32, B + 8, F0 + 8>();
-        wait_lgkm<4>(); mfma<R_ACC + 48, B + 8, F0 + 12>();
-        wait_lgkm<3>(); mfma<R_ACC + 0, B + 12, F1 + 0>();
-        wait_lgkm<2>(); mfma<R_ACC + 16, B + 12, F1 + 4>();
-        wait_lgkm<1>(); mfma<R_ACC + 32, B + 12, F1 + 8>();
-        wait_lgkm<0>(); mfma<R_ACC + 48, B + 12, F1 + 12>();
+        for_tiles<TM>([&]<int i>() { wait_lgkm<W - i>(); mfma<R_ACC + 16 * i, B + 8, F0 + 4 * i>(); });
+        if constexpr (FINAL) {
+            for_tiles<TM>([&]<int i>() {
+                wait_lgkm<TM - 1 - i>();
+                const f32x16 d = mfma_out<R_ACC + 16 * i, B + 12, F1 + 4 * i>();
+                on_tile.template operator()<i>(d);
+            });
+        } else {
+            for_tiles<TM>([&]<int i>() { wait_lgkm<TM - 1 - i>(); mfma<R_ACC + 16 * i, B + 12, F1 + 4 * i>(); });
+        }
     }
 }
 
@@ -231,72 +247,83 @@ __device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
 
 // ---- epilogue of one wave: TM pixel tiles (32 pixels each, pixel on the lane) x 32 channels (on the register index) ----
 // accumulator tile i, register r: pixel m0w + 32*i + (lane & 31), channel n_w + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
-// Its global operands are fetched BEFORE the main loop (EpiOps): stamped, the epilogue spent ~2/3 of its 5-7 k cycles waiting
-// for the shift vector and for one residual / mask load per tile, each a full memory latency with nothing else in flight.
-template <int TM> struct EpiOps {
+// * its global operands are fetched BEFORE the main loop (prefetch()): stamped, the epilogue spent ~2/3 of its 5-7 k cycles
+//   waiting for the shift vector and for one residual / mask load per tile, each a full memory latency with nothing in flight;
+// * every global access is a raw-buffer access with a 32-bit offset: rows past the end carry an out-of-range offset and are
+//   dropped by the range check (no exec masking, no 64-bit address arithmetic);
+// * tile i is finished while the last MFMAs of tiles i+1.. execute (tap_mfma FINAL).
+// PRE_RES: fetch the residual / add operand before the main loop too (32 registers live across the loop: only where the loop
+// state is small -- the multi-chunk halo kernels would spill, and their layers have no such operand in practice).
+// DG: data-gradient flavour (add operand, mask bits in, column sums out) instead of the forward one (shift, residual, ReLU,
+// sign bits out): two instantiations instead of runtime branches keep the epilogue's register footprint under the cap.
+template <int TM, bool PRE_RES, bool DG> struct Epilogue {
+    const C2Params& p;
+    unsigned m0w, slab_row;
+    int n_w;
+    bool alive;
     float sh[16];
     uint4 ra[TM], rb[TM];      // residual / add: the lane's two 16-byte pieces per tile, in STORED arrangement
     unsigned mb[TM];           // mask bits of the wave's 32 channels per tile
-};
-
-template <int TM>
-__device__ __forceinline__ void epi_prefetch(const C2Params& p, unsigned m0w, int n_w, EpiOps<TM>& e) {
-    const int lane = threadIdx.x & 63;
-    const int l31 = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.shift) s = *reinterpret_cast<const float4*>(p.shift + n_w + 8 * g + 4 * hh);
-        e.sh[4 * g] = s.x; e.sh[4 * g + 1] = s.y; e.sh[4 * g + 2] = s.z; e.sh[4 * g + 3] = s.w;
-    }
-    const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.residual);
-    const unsigned cofs = hh ? 8u : 0u;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const unsigned m = m0w + 32u * i + (unsigned)l31;
-        const bool ok = m < p.M;
-        const size_t eoff = (size_t)m * (unsigned)p.NOUT + (unsigned)n_w;
-        e.ra[i] = make_uint4(0, 0, 0, 0);
-        e.rb[i] = make_uint4(0, 0, 0, 0);
-        e.mb[i] = 0u;
-        if (res && ok) {
-            e.ra[i] = *reinterpret_cast<const uint4*>(res + eoff + cofs);
-            e.rb[i] = *reinterpret_cast<const uint4*>(res + eoff + 16 + cofs);
-        }
-        if (p.bits_in && ok) e.mb[i] = reinterpret_cast<const unsigned*>(p.bits_in)[eoff >> 5];
-    }
-}
-
-template <int TM>
-__device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int n_w, unsigned slab_row, EpiOps<TM>& e) {
-    const int lane = threadIdx.x & 63;
-    const int l31 = lane & 31, hh = lane >> 5;
     float s1[16];
+    __amdgpu_buffer_rsrc_t r_dst, r_res, r_bin, r_bout;
+
+    __device__ __forceinline__ Epilogue(const C2Params& p_, unsigned m0w_, int n_w_, unsigned slab_row_, bool alive_)
+        : p(p_), m0w(m0w_), slab_row(slab_row_), n_w(n_w_), alive(alive_) {}
+
+    __device__ __forceinline__ unsigned row_off(int i) const {      // byte offset of (pixel of tile i, channel n_w + 8 * hh) in a [M][NOUT] bf16 tensor
+        const int lane = threadIdx.x & 63;
+        const unsigned m = m0w + 32u * i + (unsigned)(lane & 31);
+        return (m < p.M && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w + ((lane >> 5) ? 8u : 0u)) * 2u : OOB;
+    }
+    __device__ __forceinline__ unsigned bit_off(int i) const {      // byte offset of the pixel's dword of 32 channel bits
+        const int lane = threadIdx.x & 63;
+        const unsigned m = m0w + 32u * i + (unsigned)(lane & 31);
+        return (m < p.M && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w) >> 3 : OOB;
+    }
+
+    __device__ __forceinline__ void prefetch() {
+        const int lane = threadIdx.x & 63;
+        const int hh = lane >> 5;
+        const unsigned out_bytes = p.M * (unsigned)p.NOUT * 2u;
+        r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
+        r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, p.residual ? out_bytes : 0u, 0x00020000);
+        r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.bits_in), 0, p.bits_in ? out_bytes >> 4 : 0u, 0x00020000);
+        r_bout = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? out_bytes >> 4 : 0u, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
-    bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(p.dst);
-    const unsigned cofs = hh ? 8u : 0u;
-    auto tile = [&]<int I>() {
-        constexpr int i = I;
-        const unsigned m = m0w + 32u * i + (unsigned)l31;
-        const bool ok = m < p.M;
-        const size_t eoff = (size_t)m * (unsigned)p.NOUT + (unsigned)n_w;
-        f32x16 acc;
-        acc_tile<I>(acc, std::make_integer_sequence<int, 16>{});
-#ifdef CS_DEBUG_V2
-        if (p.act == 100) dbg_tile<R_B + 16 * (I % 3)>(acc, std::make_integer_sequence<int, 16>{});        // raw bits of the weight buffers
-        if (p.act == 101) dbg_tile<R_AF + 16 * (I % 2)>(acc, std::make_integer_sequence<int, 16>{});       // pixel fragments
-        if (p.act == 102) dbg_tile<R_TMP>(acc, std::make_integer_sequence<int, 16>{});                     // temporaries + addresses
-#endif
+        for (int g = 0; g < 4; ++g) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!DG && p.shift && alive) s = *reinterpret_cast<const float4*>(p.shift + n_w + 8 * g + 4 * hh);
+            sh[4 * g] = s.x; sh[4 * g + 1] = s.y; sh[4 * g + 2] = s.z; sh[4 * g + 3] = s.w;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // a NULL operand has a zero-sized buffer: the loads return zeros without touching memory
+            if constexpr (PRE_RES) {
+                const unsigned off = row_off(i);
+                ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 0));
+                rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 32, 0));
+            }
+            if constexpr (DG) mb[i] = __builtin_amdgcn_raw_buffer_load_b32(r_bin, bit_off(i), 0, 0);
+        }
+    }
+
+    template <int I> __device__ __forceinline__ void operator()(const f32x16& acc) {
+        const int lane = threadIdx.x & 63;
+        const int hh = lane >> 5;
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[r] + e.sh[r];
+        for (int r = 0; r < 16; ++r) v[r] = DG ? acc[r] : acc[r] + sh[r];
         if (p.residual) {
-            uint4 ra = e.ra[i], rb = e.rb[i];
+            uint4 xa, xb;
+            if constexpr (PRE_RES) { xa = ra[I]; xb = rb[I]; }
+            else {
+                xa = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off(I), 0, 0));
+                xb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off(I), 32, 0));
+            }
             // stored arrangement -> accumulator arrangement (the swap is an involution)
-            swap32(ra.x, ra.z); swap32(ra.y, ra.w);
-            swap32(rb.x, rb.z); swap32(rb.y, rb.w);
-            const unsigned rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            swap32(xa.x, xa.z); swap32(xa.y, xa.w);
+            swap32(xb.x, xb.z); swap32(xb.y, xb.w);
+            const unsigned rw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float lo, hi;
@@ -305,19 +332,24 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
                 v[2 * k + 1] += hi;
             }
         }
-        if (p.act == CS_ACT_RELU) {
+        if (!DG && p.act == CS_ACT_RELU) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
-        if (p.bits_in) {
-            const unsigned mine = e.mb[i] >> (4 * hh);
+        if (DG && p.bits_in) {
+            const unsigned mine = mb[I] >> (4 * hh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = ((mine >> (8 * (r >> 2) + (r & 3))) & 1u) ? v[r] : 0.f;
         }
         unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        if (p.slab && ok) {
+        const unsigned off = row_off(I);
+        if constexpr (DG && I == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+        }
+        if (DG && p.slab && off != OOB) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float lo, hi;
@@ -330,19 +362,21 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
         swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
         const uint4 oa = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         const uint4 ob = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-        if (ok) {
-            *reinterpret_cast<uint4*>(dst + eoff + cofs) = oa;
-            *reinterpret_cast<uint4*>(dst + eoff + 16 + cofs) = ob;
-        }
-        if (p.bits_out) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oa), r_dst, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), r_dst, off, 32, 0);
+        if (!DG && p.bits_out) {
             // byte j of the pixel's dword = channels 8j .. 8j+7: this lane owns bytes (hh, 2 + hh)
             unsigned w = (pos_bits8(oa) | (pos_bits8(ob) << 16)) << (8 * hh);
-            w |= (unsigned)__shfl_xor((int)w, 32, 64);
-            if (ok && hh == 0) reinterpret_cast<unsigned*>(p.bits_out)[eoff >> 5] = w;
+            unsigned up = 0u;
+            swap32(w, up);                     // lanes 0-31 of `up` <- the upper half's word
+            __builtin_amdgcn_raw_buffer_store_b32(w | up, r_bout, hh ? OOB : bit_off(I), 0, 0);
         }
-    };
-    [&]<int... Is>(std::integer_sequence<int, Is...>) { (tile.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TM>{});
-    if (p.slab) {
+    }
+
+    __device__ __forceinline__ void finish() {
+        if (!DG || !p.slab || !alive) return;
+        const int lane = threadIdx.x & 63;
+        const int l31 = lane & 31, hh = lane >> 5;
         // fold the 32 pixel-lanes of each half; lane (l31 == r) keeps channel register r
         float mine1 = 0.f;
 #pragma unroll
@@ -357,13 +391,13 @@ __device__ __forceinline__ void epilogue_t(const C2Params& p, unsigned m0w, int 
             p.slab[(size_t)slab_row * 2 * p.NOUT + ch] = mine1;
         }
     }
-}
+};
 
 // =================================================================================================
 // Halo kernel: R x S taps (NTAP = R*S, a multiple of 3; S = SK), stride 1.  Workgroup = 4 waves as WM x WN;
 // wave tile = (32*TM pixels) x 32 channels; NBW = 16-row LDS blocks each wave fetches per 64-channel chunk.
 // =================================================================================================
-template <int NTAP, int SK, int TM, int WM, int WN, int NBW>
+template <int NTAP, int SK, int TM, int WM, int WN, int NBW, bool DG>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void conv2_halo_kernel(C2Params p) {
     static_assert(WM * WN == 4 && NTAP % 3 == 0 && NBW <= 8, "layout");
     constexpr int BM = WM * TM * 32, BN = WN * 32;
@@ -427,12 +461,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)p.NCC * (unsigned)(NTAP * 4096);
     const unsigned smem_base = lds_off(smem);
 
-    static_assert(TM == 4, "the register map of the main loop is laid out for 4 pixel tiles per wave");
-    EpiOps<TM> eops;
-    if (alive) epi_prefetch<TM>(p, m0w, n_w, eops);
+    static_assert(TM >= 2 && TM <= 4, "the register map of the main loop holds up to 4 pixel tiles per wave");
+    Epilogue<TM, (NBW > 5), DG> epi(p, m0w, n_w, mtile * WM + wm, alive);
+    epi.prefetch();
     CS_STAMP(4);
     own_registers();
-    vzero_seq(std::make_integer_sequence<int, 64>{});
+    vzero_seq(std::make_integer_sequence<int, 16 * TM>{});
     const unsigned hhb = (unsigned)hh * 256u;
     const unsigned cf0 = 0xf0u;
 
@@ -456,7 +490,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
         constexpr int D1 = (HN && T >= 1 && T - 1 < NBW) ? 2 : 0;
         constexpr int D2 = (HN && T >= 2 && T - 2 < NBW) ? 2 : 0;
         constexpr unsigned CUR_STAGE = ODD ? STAGE : 0u, NXT_STAGE = ODD ? 0u : STAGE;
-        constexpr int KIND = T == 0 ? 0 : (T == NTAP - 1 ? 2 : 1);
         if constexpr (has2) {
             bload4<NX2>(rsrc_b, bvoff, wsoff);
             wsoff += 4096u;
@@ -465,7 +498,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
         wait_vm<(has1 ? 4 : 0) + (has2 ? 4 : 0) + D0 + D1 + D2>();
         const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.Wp + (unsigned)(T % SK);
         const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.Wp + (unsigned)((T + 1) % SK);
-        tap_mfma<CUR, T & 1, CUR_STAGE, KIND>(qb[0], qb[1], qb[2], qb[3], sh_cur, sh_next, hhb, cf0);
+        tap_mfma<TM, CUR, T & 1, CUR_STAGE, CUR_STAGE, T == 0, T != NTAP - 1, false, (T == NTAP - 1 && !HN)>(qb[0], qb[1], qb[2 % TM], qb[3 % TM], sh_cur, sh_next,
+                                                                                                          hhb, cf0, epi);
     };
     auto chunk = [&]<bool ODD, bool HN>() {
         [&]<int... Ts>(std::integer_sequence<int, Ts...>) { (tap.template operator()<Ts, ODD, HN>(), ...); }(std::make_integer_sequence<int, NTAP>{});
@@ -486,11 +520,106 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
             }
         }
     }
-    // MFMA results -> VALU readers: the hazard padding hipcc would insert for its own MFMAs
-    asm volatile("s_nop 15\n\ts_nop 15");
     CS_STAMP(2);
-    if (!alive) return;
-    epilogue_t<TM>(p, m0w, n_w, mtile * WM + wm, eops);
+    epi.finish();
+#ifdef CS_DEBUG_V2
+    CS_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)");
+    CS_STAMP(5);
+    if (p.dbg && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
+        o[0] = t_stamp[0]; o[1] = t_stamp[4]; o[2] = t_stamp[1]; o[3] = t_stamp[2]; o[4] = t_stamp[3]; o[5] = t_stamp[5];
+    }
+#endif
+}
+
+
+// =================================================================================================
+// 1x1 convolutions with a short contraction (NCC <= 4 chunks of 64 channels): the whole BM x C pixel tile is staged ONCE,
+// one barrier per workgroup; a "tap" of the shared main loop is the next 64-channel chunk.  Forward with any stride (the
+// down-sampling 1x1 of model/resnet.py:183 gathers every stride-th pixel) and stride-1 data gradients.
+// =================================================================================================
+template <int NCC, int TM, int WM, int WN, bool DG>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void conv2_gemm_kernel(C2Params p) {
+    static_assert(WM * WN == 4 && NCC >= 1 && NCC <= 4 && TM >= 2 && TM <= 4, "layout");
+    constexpr int BM = WM * TM * 32, BN = WN * 32;
+    constexpr int NBW = BM / 64;                   // 16-row blocks per wave per chunk
+    constexpr unsigned CHB = BM * 128;             // bytes of one chunk of the tile
+    static_assert((NCC - 1) * CHB + 1536 < 65536, "ds_read offset field");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+#ifdef CS_DEBUG_V2
+    unsigned long long t_stamp[6];
+    CS_STAMP(0);
+#endif
+    const unsigned bid = blockIdx.x;
+    const unsigned slot = bid >> 3;
+    const unsigned mtile = (slot / (unsigned)p.n_ntiles) * 8u + (bid & 7u);
+    const unsigned m0 = mtile * BM;
+    if (m0 >= p.M) return;
+    const int n0 = (int)(slot % (unsigned)p.n_ntiles) * BN;
+    const int n_w = n0 + wn * 32;
+    const bool alive = n_w < p.NOUT;
+    const unsigned m0w = m0 + (unsigned)(wm * TM * 32);
+
+    // rows of the LDS image = pixels of the tile in order; this lane's operand rows
+    unsigned qb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qb[i] = (unsigned)((wm * TM + (i < TM ? i : 0)) * 32 + l31);
+    unsigned voff[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const unsigned m = m0 + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+        unsigned pix = m;
+        if (p.stride > 1) {
+            const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+            const unsigned x = m - yall * (unsigned)p.DW;
+            const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+            const unsigned y = yall - n * (unsigned)p.DH;
+            pix = (n * (unsigned)p.SH + y * (unsigned)p.stride) * (unsigned)p.SW + x * (unsigned)p.stride;
+        }
+        voff[j] = m < p.M ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+    }
+    const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
+    const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
+    const unsigned bvoff = alive ? (unsigned)lane * 16u : OOB;
+    unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)(NCC * 4096);
+    const unsigned smem_base = lds_off(smem);
+
+    Epilogue<TM, true, DG> epi(p, m0w, n_w, mtile * WM + wm, alive);
+    epi.prefetch();
+    CS_STAMP(4);
+    own_registers();
+    vzero_seq(std::make_integer_sequence<int, 16 * TM>{});
+    const unsigned hhb = (unsigned)hh * 256u;
+    const unsigned cf0 = 0xf0u;
+
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+            dma_block(rsrc_a, smem_base + (unsigned)cc * CHB + (unsigned)(wave + 4 * j) * 2048u, voff[j], (unsigned)cc * 128u);
+    bload4<0>(rsrc_b, bvoff, wsoff); wsoff += 4096u;
+    if constexpr (NCC > 1) { bload4<1>(rsrc_b, bvoff, wsoff); wsoff += 4096u; }
+    wait_vm<(NCC > 1 ? 8 : 4)>();
+    raw_barrier();
+    CS_STAMP(1);
+
+    auto tap = [&]<int T>() {
+        if constexpr (T + 2 < NCC) {
+            bload4<(T + 2) % 3>(rsrc_b, bvoff, wsoff);
+            wsoff += 4096u;
+        }
+        wait_vm<(T + 1 < NCC ? 4 : 0) + (T + 2 < NCC ? 4 : 0)>();
+        tap_mfma<TM, T % 3, 0, T * CHB, (T + 1) * CHB, T == 0, T != NCC - 1, true, T == NCC - 1>(qb[0], qb[1], qb[2], qb[3], 0u, 0u, hhb, cf0, epi);
+    };
+    [&]<int... Ts>(std::integer_sequence<int, Ts...>) { (tap.template operator()<Ts>(), ...); }(std::make_integer_sequence<int, NCC>{});
+    CS_STAMP(2);
+    epi.finish();
 #ifdef CS_DEBUG_V2
     CS_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)");
@@ -595,12 +724,81 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     return true;
 }
 
-template <int NBW>
+bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
+    if (g_v2_off) return false;
+    if (g->R != 1 || g->S != 1 || g->pad != 0 || g->stride < 1) return false;
+    if (dgrad && g->stride != 1) return false;
+    const int SC = dgrad ? g->K : g->C, NOUT = dgrad ? g->C : g->K;
+    const int SH = dgrad ? g->P : g->H, SW = dgrad ? g->Q : g->W;
+    const int DH = dgrad ? g->H : g->P, DW = dgrad ? g->W : g->Q;
+    if (SC % 64 || NOUT % 64 || DH < 1 || DW < 1) return false;
+    if (g->stride > 1 && (DH < 2 || DW < 2)) return false;
+    const int ncc = SC / 64;
+    if (ncc > 4) return false;
+    const long long M = (long long)g->N * DH * DW;
+    const unsigned long long src_bytes = (unsigned long long)g->N * SH * SW * SC * 2ull;
+    if (M >= (1ll << 31) - 512 || src_bytes >= 0x80000000ull) return false;
+    int cfg = 0;
+    if (NOUT % 128 == 0) cfg = 3;                       // 128 px x 128 ch, 1 x 4 waves of 4 tiles
+    else if (NOUT == 64) cfg = ncc <= 2 ? 4 : 5;        // 2 x 2 waves: 256 px (4 tiles) / 128 px (2 tiles) x 64 ch
+    if (!cfg) return false;
+    C2Params& p = pl.p;
+    p = C2Params{};
+    p.SH = SH; p.SW = SW; p.SC = SC; p.NS = g->N;
+    p.DH = DH; p.DW = DW; p.NOUT = NOUT;
+    p.stride = g->stride;
+    if (g->stride > 1) {
+        magic((unsigned)DW, p.mg_dw, p.sh_dw);
+        magic((unsigned)DH, p.mg_dh, p.sh_dh);
+    }
+    p.NCC = ncc;
+    p.M = (unsigned)M;
+    p.src_bytes = (unsigned)src_bytes;
+    p.pix_bytes = (unsigned)SC * 2u;
+    const unsigned long long wbytes = (unsigned long long)cs_ceil_div(NOUT, 32) * 32 * (unsigned long long)SC * 2ull;
+    if (wbytes >= 0x80000000ull) return false;
+    p.wpk_bytes = (unsigned)wbytes;
+    const int BM = cfg == 4 ? 256 : 128, BN = cfg == 3 ? 128 : 64;
+    p.n_ntiles = cs_ceil_div(NOUT, BN);
+    pl.cfg = cfg; pl.nbw = 0; pl.ncc = ncc;
+    pl.rows = cs_ceil_div(M, BM) * (cfg == 3 ? 1 : 2);
+    return true;
+}
+
+template <int NCC, int TM, int WM, int WN, bool DG>
+int launch_gemm_t(const C2Params& p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, BM);
+    dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
+    char name[64];
+    snprintf(name, sizeof(name), "conv2_gemm_kernel<%d,%d,%d,%d,%s>", NCC, TM, WM, WN, DG ? "true" : "false");
+    cs_set_variant_(name);
+    hipLaunchKernelGGL((conv2_gemm_kernel<NCC, TM, WM, WN, DG>), grid, dim3(256), (size_t)NCC * BM * 128, st, p);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+template <bool DG>
+int launch_gemm(const C2Plan& pl, hipStream_t st) {
+    const C2Params& p = pl.p;
+    if (pl.cfg == 3) {
+        switch (pl.ncc) {
+            case 1: return launch_gemm_t<1, 4, 1, 4, DG>(p, st);
+            case 2: return launch_gemm_t<2, 4, 1, 4, DG>(p, st);
+            case 3: return launch_gemm_t<3, 4, 1, 4, DG>(p, st);
+            default: return launch_gemm_t<4, 4, 1, 4, DG>(p, st);
+        }
+    }
+    if (pl.cfg == 4) return pl.ncc == 1 ? launch_gemm_t<1, 4, 2, 2, DG>(p, st) : launch_gemm_t<2, 4, 2, 2, DG>(p, st);
+    return pl.ncc == 3 ? launch_gemm_t<3, 2, 2, 2, DG>(p, st) : launch_gemm_t<4, 2, 2, 2, DG>(p, st);
+}
+
+template <int NBW, bool DG>
 int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
     const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 128);
     dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
     const size_t lds = (size_t)NBW * 8192 * (two_stage ? 2 : 1);
-    auto fn = conv2_halo_kernel<9, 3, 4, 1, 4, NBW>;
+    auto fn = conv2_halo_kernel<9, 3, 4, 1, 4, NBW, DG>;
     if (lds > 65536) {
         static bool raised = false;
         if (!raised) {
@@ -612,29 +810,30 @@ int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
         }
     }
     char name[64];
-    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,4,1,4,%d>", NBW);
+    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,4,1,4,%d,%s>", NBW, DG ? "true" : "false");
     cs_set_variant_(name);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
 
+template <bool DG>
 int launch_halo(const C2Plan& pl, hipStream_t st) {
     const C2Params& p = pl.p;
     if (pl.cfg == 2) {
         const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 256);
         dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
-        cs_set_variant_("conv2_halo_kernel<9,3,4,2,2,8>");
-        hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8>), grid, dim3(256), 8 * 8192, st, p);
+        cs_set_variant_(DG ? "conv2_halo_kernel<9,3,4,2,2,8,true>" : "conv2_halo_kernel<9,3,4,2,2,8,false>");
+        hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8, DG>), grid, dim3(256), 8 * 8192, st, p);
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
     const int two = pl.ncc > 1;
     switch (pl.nbw) {
-        case 3: return launch_cfg1<3>(p, st, two);
-        case 4: return launch_cfg1<4>(p, st, two);
-        case 5: return launch_cfg1<5>(p, st, two);
-        default: return launch_cfg1<8>(p, st, 0);
+        case 3: return launch_cfg1<3, DG>(p, st, two);
+        case 4: return launch_cfg1<4, DG>(p, st, two);
+        case 5: return launch_cfg1<5, DG>(p, st, two);
+        default: return launch_cfg1<8, DG>(p, st, 0);
     }
 }
 
@@ -649,10 +848,16 @@ extern "C" int cs_debug_set_stamp_buffer(void* p) { g_dbg_buf = reinterpret_cast
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
+static bool plan_any(const CsConvGeom* g, int dgrad, C2Plan& pl) { return plan_halo(g, dgrad, pl) || plan_gemm(g, dgrad, pl); }
+static int launch_any(const C2Plan& pl, hipStream_t st, bool dg) {
+    if (dg) return pl.cfg <= 2 ? launch_halo<true>(pl, st) : launch_gemm<true>(pl, st);
+    return pl.cfg <= 2 ? launch_halo<false>(pl, st) : launch_gemm<false>(pl, st);
+}
+
 extern "C" int cs_conv2d_packed_supported(const CsConvGeom* g, int dgrad) {
     if (!g) return 0;
     C2Plan pl;
-    return plan_halo(g, dgrad, pl) ? 1 : 0;
+    return plan_any(g, dgrad, pl) ? 1 : 0;
 }
 
 extern "C" size_t cs_conv2d_packed_weight_bytes(const CsConvGeom* g, int dgrad) {
@@ -676,7 +881,7 @@ extern "C" int cs_pack_conv_weights(const CsConvGeom* g, int dgrad, const void* 
 
 extern "C" int cs_conv2d_packed_partial_rows(const CsConvGeom* g, int dgrad) {
     C2Plan pl;
-    if (!g || !plan_halo(g, dgrad, pl)) return 0;
+    if (!g || !plan_any(g, dgrad, pl)) return 0;
     return pl.rows;
 }
 
@@ -687,7 +892,7 @@ extern "C" int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const vo
     CS_CHECK_ARG(act == CS_ACT_NONE || act == CS_ACT_RELU, "conv2d_fwd_packed: activation must be none or ReLU");
 #endif
     C2Plan pl;
-    if (!plan_halo(g, 0, pl)) {
+    if (!plan_any(g, 0, pl)) {
         cs_set_error_("conv2d_fwd_packed: geometry not served by the packed-operand kernel (ask cs_conv2d_packed_supported first)");
         return CS_ERR_UNSUPPORTED;
     }
@@ -697,14 +902,14 @@ extern "C" int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const vo
 #ifdef CS_DEBUG_V2
     pl.p.dbg = g_dbg_buf;
 #endif
-    return launch_halo(pl, reinterpret_cast<hipStream_t>(stream));
+    return launch_any(pl, reinterpret_cast<hipStream_t>(stream), false);
 }
 
 extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, const uint8_t* mask_bits,
                                       void* dx, float* partial_rows, void* stream) {
     CS_CHECK_ARG(g && dy && w_packed && dx, "conv2d_dgrad_packed: NULL tensor");
     C2Plan pl;
-    if (!plan_halo(g, 1, pl)) {
+    if (!plan_any(g, 1, pl)) {
         cs_set_error_("conv2d_dgrad_packed: geometry not served by the packed-operand kernel (ask cs_conv2d_packed_supported first)");
         return CS_ERR_UNSUPPORTED;
     }
@@ -715,5 +920,5 @@ extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const
 #ifdef CS_DEBUG_V2
     pl.p.dbg = g_dbg_buf;
 #endif
-    return launch_halo(pl, reinterpret_cast<hipStream_t>(stream));
+    return launch_any(pl, reinterpret_cast<hipStream_t>(stream), true);
 }

@@ -15,17 +15,25 @@ from cellsegmentation_amd import kernels as K  # noqa: E402
 BF = torch.bfloat16
 TOL = 1e-2
 
-#        N   H   W  Cin Cout pad   (3x3, stride 1)
+#        N   H   W  Cin Cout R  s  pad
 SHAPES = [
-    (2, 19, 19, 64, 128, 1),      # one chunk, window blocks: cold start + last tap only
-    (3, 10, 10, 128, 128, 1),     # two chunks, tiles straddle images (100 px per image)
-    (2, 38, 38, 128, 256, 1),     # two N tiles
-    (1, 19, 19, 256, 128, 1),     # four chunks: both stages, odd/even chunk bodies
-    (2, 75, 75, 64, 64, 1),       # 256 x 64 tile configuration (2 x 2 waves), M tail
-    (5, 7, 9, 64, 128, 1),        # non-square, tiny images
-    (2, 12, 12, 64, 128, 0),      # valid convolution: the data gradient's source is smaller than its destination
-    (2, 9, 9, 64, 128, 2),        # pad 2: output larger than input
-    (3, 21, 17, 192, 128, 1),     # three chunks
+    (2, 19, 19, 64, 128, 3, 1, 1),      # one chunk, window blocks: cold start + last tap only
+    (3, 10, 10, 128, 128, 3, 1, 1),     # two chunks, tiles straddle images (100 px per image)
+    (2, 38, 38, 128, 256, 3, 1, 1),     # two N tiles
+    (1, 19, 19, 256, 128, 3, 1, 1),     # four chunks: both stages, odd/even chunk bodies
+    (2, 75, 75, 64, 64, 3, 1, 1),       # 256 x 64 tile configuration (2 x 2 waves), M tail
+    (5, 7, 9, 64, 128, 3, 1, 1),        # non-square, tiny images
+    (2, 12, 12, 64, 128, 3, 1, 0),      # valid convolution: the data gradient's source is smaller than its destination
+    (2, 9, 9, 64, 128, 3, 1, 2),        # pad 2: output larger than input
+    (3, 21, 17, 192, 128, 3, 1, 1),     # three chunks
+    # 1x1: the whole pixel tile staged once (contraction <= 256 channels)
+    (2, 19, 19, 64, 256, 1, 1, 0),      # one chunk; data gradient: four chunks into 64 channels (2 x 2 waves of 2 tiles)
+    (3, 21, 17, 256, 64, 1, 1, 0),      # four chunks into 64 channels; data gradient: one chunk, 1 x 4 waves
+    (2, 38, 38, 128, 512, 1, 1, 0),     # two chunks, four N tiles; data gradient not served (contraction 512)
+    (2, 19, 19, 192, 128, 1, 1, 0),     # three chunks
+    (2, 75, 75, 64, 64, 1, 1, 0),       # 256 px x 64 ch tiles
+    (2, 38, 38, 128, 64, 1, 1, 0),      # two chunks, 256 px x 64 ch tiles
+    (2, 37, 41, 256, 128, 1, 2, 0),     # the strided down-sampling 1x1 (forward only)
 ]
 
 
@@ -63,11 +71,11 @@ def _pack_bits(mask_nchw, dev):
 
 @pytest.mark.parametrize("shape", SHAPES)
 def test_packed_fwd_and_dgrad(shape, dev):
-    N, H, W, Cin, Cout, pad = shape
-    g = torch.Generator().manual_seed(77 + H * 3 + Cin + Cout)
+    N, H, W, Cin, Cout, R, stride, pad = shape
+    g = torch.Generator().manual_seed(77 + H * 3 + Cin + Cout + R)
     x = _q(torch.randn((N, Cin, H, W), generator=g))
-    w = _q(torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5)
-    geom = K.make_geom(N, H, W, Cin, Cout, 3, 3, 1, pad)
+    w = _q(torch.randn((Cout, Cin, R, R), generator=g) / (Cin * R * R) ** 0.5)
+    geom = K.make_geom(N, H, W, Cin, Cout, R, R, stride, pad)
     P, Q = geom.P, geom.Q
     w_khwc, w_chwk = K.weight_prep(w.to(dev), None, BF, Cin, Cout, want_fwd=True, want_bwd=True)
 
@@ -75,7 +83,7 @@ def test_packed_fwd_and_dgrad(shape, dev):
     if K.packed_supported(geom, BF, dgrad=False):
         shift = torch.randn((Cout,), generator=g) * 0.1
         res = _q(torch.randn((N, Cout, P, Q), generator=g))
-        ref = F.conv2d(x, w, padding=pad)
+        ref = F.conv2d(x, w, stride=stride, padding=pad)
         ref_full = torch.relu(ref + shift.view(1, -1, 1, 1) + res)
         xd = _nhwc(x, dev)
         wp = K.pack_conv_weights(geom, w_khwc, dgrad=False)
@@ -91,14 +99,14 @@ def test_packed_fwd_and_dgrad(shape, dev):
         torch.cuda.synchronize()
         assert _relerr(_from_nhwc(y_plain), _from_nhwc(y_old)) < TOL
     else:
-        assert Cout % 64 != 0 or Cin % 64 != 0 or (Cout == 64 and Cin > 64), f"{shape}: forward unexpectedly not served"
+        assert Cout % 64 != 0 or Cin % 64 != 0 or (Cout == 64 and Cin > 64 and R == 3), f"{shape}: forward unexpectedly not served"
 
     # ---------- data gradient
     if K.packed_supported(geom, BF, dgrad=True):
         dy = _q(torch.randn((N, Cout, P, Q), generator=g))
         add = _q(torch.randn((N, Cin, H, W), generator=g))
         mask = torch.rand((N, Cin, H, W), generator=g) > 0.4
-        ref_dx = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, stride=1, padding=pad)
+        ref_dx = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, stride=stride, padding=pad)
         ref_dx2 = (ref_dx + add) * mask
         dyd = _nhwc(dy, dev)
         wpd = K.pack_conv_weights(geom, w_chwk, dgrad=True)
@@ -115,6 +123,8 @@ def test_packed_fwd_and_dgrad(shape, dev):
 
 def test_packed_declines_what_it_does_not_serve(dev):
     assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 2, 1), BF)          # stride 2
+    assert not K.packed_supported(K.make_geom(2, 19, 19, 128, 64, 1, 1, 2, 0), BF, dgrad=True)      # strided 1x1 data gradient
+    assert not K.packed_supported(K.make_geom(2, 19, 19, 512, 128, 1, 1, 1, 0), BF)         # contraction > 256 channels (ring variant)
     assert not K.packed_supported(K.make_geom(2, 19, 19, 24, 128, 3, 3, 1, 1), BF)          # channels not a multiple of 64
     assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 1, 1), torch.float32)
     assert not K.packed_supported(K.make_geom(2, 1, 1, 64, 128, 3, 3, 1, 1), BF)            # 1x1 images (32x32 tiles at layer4)

@@ -15,7 +15,14 @@ SHAPES = {
     "l2_3x3": (64, 38, 38, 128, 128, 3, 1, 1),
     "l3_3x3": (64, 19, 19, 256, 256, 3, 1, 1),
     "l4_3x3": (64, 10, 10, 512, 512, 3, 1, 1),
+    "l1_1x1_64_64": (64, 75, 75, 64, 64, 1, 1, 0),
     "l1_1x1_64_256": (64, 75, 75, 64, 256, 1, 1, 0),
+    "l2_1x1_256_128": (64, 75, 75, 256, 128, 1, 1, 0),
+    "l2_1x1_128_512": (64, 38, 38, 128, 512, 1, 1, 0),
+    "l2_1x1_512_128": (64, 38, 38, 512, 128, 1, 1, 0),
+    "l3_1x1_256_1024": (64, 19, 19, 256, 1024, 1, 1, 0),
+    "l4_1x1_512_2048": (64, 10, 10, 512, 2048, 1, 1, 0),
+    "l4_1x1_2048_512": (64, 10, 10, 2048, 512, 1, 1, 0),
     "l1_1x1_256_64": (64, 75, 75, 256, 64, 1, 1, 0),
     "l3_1x1_1024_256": (64, 19, 19, 1024, 256, 1, 1, 0),
     "l2_3x3_s2": (64, 75, 75, 128, 128, 3, 2, 1),
@@ -47,7 +54,10 @@ def main():
             cases = [c for c in cases if c[0] in os.environ["ONLY"].split(",")]
         if dt == torch.bfloat16 and K.packed_supported(g, dt, False):
             wpk = K.pack_conv_weights(g, wk, False)
-            cases.append(("fwd_pk", lambda: K.conv_fwd_packed(g, x, wpk, shift, None, K.CS_ACT_RELU, want_bits=True)))
+            resid = torch.randn((N, g.P, g.Q, Kc), device=dev).to(dt) if os.environ.get("RESID") else None
+            cases.append(("fwd_pk", lambda: K.conv_fwd_packed(g, x, wpk, shift, resid, K.CS_ACT_RELU, want_bits=True)))
+            if resid is not None:
+                cases[0] = ("fwd", lambda: K.conv_fwd(g, x, wk, None, shift, resid, K.CS_ACT_RELU, want_bits=True))
         if dt == torch.bfloat16 and K.packed_supported(g, dt, True):
             wpd = K.pack_conv_weights(g, wc, True)
             mb = torch.randint(0, 255, (N, H, W, C // 8), dtype=torch.uint8, device=dev)

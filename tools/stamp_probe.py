@@ -18,20 +18,21 @@ for name in sys.argv[1:] or ["l1_3x3", "l2_3x3", "l3_3x3", "l4_3x3"]:
     wk, wc = K.weight_prep(w, None, torch.bfloat16, C, Kc, True, True)
     wp = K.pack_conv_weights(g, wk, False)
     shift = torch.zeros((Kc,), device=dev)
-    nblk = 8 * ((N * H * W + 127) // 128 + 8) * max(1, Kc // 64)
+    nblk = 8 * ((N * g.P * g.Q + 127) // 128 + 8) * max(1, Kc // 64)
     buf = torch.zeros((nblk, 4, 6), dtype=torch.int64, device=dev)
+    resid = torch.randn((N, g.P, g.Q, Kc), device=dev).to(torch.bfloat16) if os.environ.get("RESID") else None
     for _ in range(3):
-        K.conv_fwd_packed(g, x, wp, shift, None, K.CS_ACT_RELU, want_bits=True)
+        K.conv_fwd_packed(g, x, wp, shift, resid, K.CS_ACT_RELU, want_bits=True)
     torch.cuda.synchronize()
     lib.cs_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
-    K.conv_fwd_packed(g, x, wp, shift, None, K.CS_ACT_RELU, want_bits=True)
+    K.conv_fwd_packed(g, x, wp, shift, resid, K.CS_ACT_RELU, want_bits=True)
     torch.cuda.synchronize()
     lib.cs_debug_set_stamp_buffer(None)
     b = buf.cpu().reshape(-1, 6)
     b = b[b[:, 0] != 0].double()
     d = [b[:, i + 1] - b[:, i] for i in range(5)]
     ncc = C // 64
-    ideal = ncc * 9 * 16 * 32
+    ideal = ncc * R * R * 16 * 32
     names = ["index math", "first loads + barrier", "main loop", "epilogue issue", "store drain"]
     print(f"{name}: waves {len(b)}, main loop alone = {ideal} MFMA cycles; total med {(b[:, 5] - b[:, 0]).median():.0f}")
     for n_, v in zip(names, d):
