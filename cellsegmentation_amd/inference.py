@@ -70,8 +70,13 @@ def sample(trainset, probs, tiles_per_pos, topk_neg, pos_neg_ratio):
 
 def inference_image(loader, model, device, epoch=None, total_epochs=None, mode='train', cls_limit=False, return_id=False,
                     categorize=None, de_categorize=None):
-    """Image-level class + rounded count (inference.py:46-101).  ``categorize``/``de_categorize`` are the
-    dataset helpers the reference imports (dataset/dataset.py:745-780); only needed with cls_limit."""
+    """Image-level class + rounded count (inference.py:46-101).  ``categorize``/``de_categorize`` are the dataset helpers the
+    reference imports at module level (inference.py:6, dataset/dataset.py:745-780); only needed with cls_limit, and then taken
+    from the caller's ``dataset`` module when not passed."""
+    if cls_limit and (categorize is None or de_categorize is None):
+        import dataset as _dataset                       # the reference's (or the user's) dataset module, as inference.py:6
+        categorize = categorize or _dataset.categorize
+        de_categorize = de_categorize or _dataset.de_categorize
     model.eval()
     ids, cats, counts = [], [], []
     with torch.no_grad():
@@ -97,6 +102,32 @@ def inference_image(loader, model, device, epoch=None, total_epochs=None, mode='
     if return_id:
         return (np.concatenate(ids) if ids else np.array(())), cats, counts
     return cats, counts
+
+
+def inference_image_cls(loader, model, device, epoch=None, total_epochs=None, mode='train'):
+    """Image-level class only (inference.py:104-120): argmax of the 7-way head."""
+    model.eval()
+    cats = []
+    with torch.no_grad():
+        for i, data in enumerate(tqdm(loader, desc="image forwarding")):
+            if mode == 'train':
+                data = data[0]
+            output = model(data.to(device))
+            cats.append(torch.argmax(output[0], dim=1).cpu().numpy().astype(np.float64))     # argmax of softmax == argmax of logits
+    return np.concatenate(cats) if cats else np.array(())
+
+
+def inference_image_reg(loader, model, device, epoch=None, total_epochs=None, mode='train'):
+    """Image-level count only (inference.py:123-137): the raw regression output, float32 [len(dataset)]."""
+    model.eval()
+    nums = []
+    with torch.no_grad():
+        for i, data in enumerate(tqdm(loader, desc="image forwarding")):
+            if mode == 'train':
+                data = data[0]
+            output = model(data.to(device))
+            nums.append(output[1].detach()[:, 0].float().cpu())
+    return torch.cat(nums, dim=0).numpy() if nums else torch.tensor(()).numpy()
 
 
 def inference_seg(loader, model, device, mode='train'):
