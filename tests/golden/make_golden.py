@@ -248,8 +248,9 @@ def setmode_groups(out):
     except Exception as e:  # noqa: BLE001
         out["setmode/invalid_msg"] = np.array(str(e))
     net.mode = None
+    net.eval()          # train-mode BatchNorm would raise its own "Expected more than 1 value per channel" first
     try:
-        net(torch.zeros(1, 3, 32, 32))
+        net(torch.zeros(2, 3, 32, 32))
     except Exception as e:  # noqa: BLE001
         out["forward/unset_msg"] = np.array(str(e))
 
