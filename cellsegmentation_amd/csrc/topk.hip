@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int kMaxRun = 8192;   // 64 KiB of u64 keys
+constexpr int kMaxRun = 8192;   // longest run the LDS kernel sorts (64 KiB of u64 keys); longer runs: run_sort_global_kernel
 
 __device__ __forceinline__ uint32_t orderable(float f) {
     if (f != f) return 0xffffffffu;          // NaN sorts last (numpy)
@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void run_sort_kernel(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
     const int64_t beg = seg_off[blockIdx.x];
-    const int n = (int)(seg_off[blockIdx.x + 1] - beg);
-    if (n <= 0) return;
+    const int64_t n64 = seg_off[blockIdx.x + 1] - beg;
+    if (n64 <= 0 || n64 > kMaxRun) return;       // long runs belong to run_sort_global_kernel
+    const int n = (int)n64;
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (int i = threadIdx.x; i < np2; i += blockDim.x)
@@ -45,6 +46,62 @@ __global__ __launch_bounds__(256) void run_sort_kernel(const float* __restrict__
         }
     }
     for (int i = threadIdx.x; i < n; i += blockDim.x) order[beg + i] = beg + (int64_t)(keys[i] & 0xffffffffull);
+}
+
+// Runs longer than kMaxRun (the reference has no limit: inference.py:34-41 sorts whatever the dataset holds, e.g. whole-slide
+// tile grids): the same stable sort IN PLACE in global memory, one workgroup per run.  The 64-bit keys live in the run's own
+// slice of `order` (8 bytes per tile, like the result), so no extra workspace; the network is the all-ascending form of the
+// bitonic sorter (first step of each merge compares with the MIRROR position i ^ (k-1), the rest with i ^ j), in which the
+// virtual +inf padding of a non-power-of-two run never moves and is simply skipped.  Every access is an agent-scope atomic
+// (L2-served: another wave's store must not be shadowed by a stale L1 line), stages are separated by workgroup barriers.
+__global__ __launch_bounds__(1024) void run_sort_global_kernel(const float* __restrict__ probs, const int64_t* __restrict__ seg_off,
+                                                               int64_t* __restrict__ order) {
+    const int64_t beg = seg_off[blockIdx.x];
+    const int64_t n = seg_off[blockIdx.x + 1] - beg;
+    if (n <= kMaxRun) return;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(order + beg);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+        __hip_atomic_store(keys + i, ((unsigned long long)orderable(probs[beg + i]) << 32) | (unsigned long long)(unsigned)i, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int64_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    auto pass = [&](int64_t mask) {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const int64_t p = i ^ mask;
+            if (p > i && p < n) {
+                const unsigned long long a = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long b = __hip_atomic_load(keys + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a > b) {
+                    __hip_atomic_store(keys + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(keys + p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int64_t k = 2; k <= np2; k <<= 1) {
+        pass(k - 1);
+        for (int64_t j = k >> 2; j > 0; j >>= 1) pass(j);
+    }
+    // keys -> tile indices (each element is rewritten by the thread that reads it)
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long kv = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        order[beg + i] = beg + (int64_t)(kv & 0xffffffffull);
+    }
+}
+
+int launch_run_sort(const float* probs, const int64_t* seg_offsets, int n_groups, int max_run, int64_t* order, hipStream_t st) {
+    const int lds_run = max_run < kMaxRun ? max_run : kMaxRun;
+    int np2 = 1;
+    while (np2 < lds_run) np2 <<= 1;
+    hipLaunchKernelGGL(run_sort_kernel, dim3(n_groups), dim3(256), (size_t)np2 * 8, st, probs, seg_offsets, order);
+    CS_LAUNCH_CHECK();
+    if (max_run > kMaxRun) {
+        hipLaunchKernelGGL(run_sort_global_kernel, dim3(n_groups), dim3(1024), 0, st, probs, seg_offsets, order);
+        CS_LAUNCH_CHECK();
+    }
+    return CS_OK;
 }
 
 // Selection predicate over SORTED positions.  kpt != NULL: the reference's wrap-around top-k test (inference.py:38-41);
@@ -148,17 +205,12 @@ extern "C" int cs_segmented_topk(const float* probs, const int32_t* groups, cons
     CS_CHECK_ARG(probs && groups && k_per_tile && seg_offsets && out_idx && out_count && workspace, "segmented_topk: NULL argument");
     CS_CHECK_ARG(T > 0 && n_groups > 0 && max_run > 0, "segmented_topk: empty input");
     CS_CHECK_ARG(workspace_bytes >= cs_segmented_topk_workspace(T), "segmented_topk: workspace too small");
-    if (max_run > kMaxRun) {
-        cs_set_error_("segmented_topk: a group has more than 8192 tiles (LDS sort limit)");
-        return CS_ERR_UNSUPPORTED;
-    }
+    CS_CHECK_ARG(max_run < (1 << 30), "segmented_topk: run length out of range");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int64_t* order = reinterpret_cast<int64_t*>(workspace);
     int32_t* block_cnt = reinterpret_cast<int32_t*>(order + T);
-    int np2 = 1;
-    while (np2 < max_run) np2 <<= 1;
-    hipLaunchKernelGGL(run_sort_kernel, dim3(n_groups), dim3(256), (size_t)np2 * 8, st, probs, seg_offsets, order);
-    CS_LAUNCH_CHECK();
+    const int rc = launch_run_sort(probs, seg_offsets, n_groups, max_run, order, st);
+    if (rc != CS_OK) return rc;
     const int nb = (int)((T + kItems - 1) / kItems);
     const SelPred q{groups, k_per_tile, nullptr, nullptr, 0.f};
     hipLaunchKernelGGL(sel_count_kernel, dim3(nb), dim3(256), 0, st, q, T, block_cnt);
@@ -270,16 +322,8 @@ __global__ __launch_bounds__(256) void prune_kernel(const int32_t* __restrict__ 
 extern "C" int cs_segmented_order(const float* probs, const int64_t* seg_offsets, int n_groups, int max_run, long long T,
                                   int64_t* order, void* stream) {
     CS_CHECK_ARG(probs && seg_offsets && order && T > 0 && n_groups > 0 && max_run > 0, "segmented_order: bad arguments");
-    if (max_run > kMaxRun) {
-        cs_set_error_("segmented_order: a group has more than 8192 tiles (LDS sort limit)");
-        return CS_ERR_UNSUPPORTED;
-    }
-    int np2 = 1;
-    while (np2 < max_run) np2 <<= 1;
-    hipLaunchKernelGGL(run_sort_kernel, dim3(n_groups), dim3(256), (size_t)np2 * 8, reinterpret_cast<hipStream_t>(stream), probs, seg_offsets,
-                       order);
-    CS_LAUNCH_CHECK();
-    return CS_OK;
+    CS_CHECK_ARG(max_run < (1 << 30), "segmented_order: run length out of range");
+    return launch_run_sort(probs, seg_offsets, n_groups, max_run, order, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int cs_threshold_select(const float* probs, const int64_t* order, long long T, float threshold, int64_t* out_idx,

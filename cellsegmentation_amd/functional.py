@@ -131,6 +131,9 @@ class _AffineRows(torch.autograd.Function):
 def batch_norm_rows(x, bn, act=K.CS_ACT_NONE):
     """nn.BatchNorm1d forward on GPU rows; honours bn.training."""
     if bn.training:
+        if x.shape[0] == 1:
+            # nn.BatchNorm1d (resnet.py:134,138) refuses a single row in train mode; a ragged last batch must fail as loudly here
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")
         momentum = bn.momentum if bn.momentum is not None else 0.1
         y = _BatchNormRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, act)
         if bn.num_batches_tracked is not None:
@@ -180,7 +183,7 @@ class _Dice(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, t, eps, mean):
         if p.ndim == 2 and t.ndim == 2:          # metrics/metrics.py:39-44: one global dice
-            p2, t2 = p.contiguous().view(1, -1), t.contiguous().view(1, -1)
+            p2, t2 = p.contiguous().view(1, -1), t.contiguous().view(1, -1).float()
         else:
             p2 = p.contiguous().view(p.shape[0], -1)
             t2 = t.contiguous().view(t.shape[0], -1).float()

@@ -298,7 +298,8 @@ int cs_softmax_channel_bwd(const float* logits, const float* dpc, float* dlogits
  * probs[T] fp32, groups[T] int32 non-decreasing, k_per_tile[T] int32 (k of the tile's group).
  * seg_offsets[n_groups+1] int64 (device): start of each group's run; max_run = longest run (host int).
  * Writes the reference's order[index] list: out_idx[0..*out_count) int64 (device), reproducing
- * np.lexsort((probs, groups)) + the wrap-around (i+k)%T comparison bit-exactly.
+ * np.lexsort((probs, groups)) + the wrap-around (i+k)%T comparison bit-exactly.  Runs of any length: up to 8192 tiles are
+ * sorted in LDS, longer ones (whole-slide tile grids) in place in global memory -- the reference has no limit either.
  * workspace: >= cs_segmented_topk_workspace(T) bytes. */
 size_t cs_segmented_topk_workspace(long long T);
 int cs_segmented_topk(const float* probs, const int32_t* groups, const int32_t* k_per_tile,

@@ -155,6 +155,25 @@ def test_topk_random_ragged_with_ties(seed, dev):
         assert got.tolist() == ref.tolist()
 
 
+def test_topk_runs_longer_than_the_lds_sort(dev):
+    """The reference sorts whatever the dataset holds (inference.py:34-41): images with more than 8192 tiles (whole-slide grids)
+    take the in-place global-memory sorter; mixed with short runs, heavy ties, a non-power-of-two and an exact power-of-two run."""
+    rs = np.random.RandomState(11)
+    sizes = np.array([100, 8193, 7, 20000, 8192, 16384, 1])
+    groups = np.repeat(np.arange(len(sizes)), sizes)
+    labels = {g: int(rs.choice([0, 1, 3, 50])) for g in range(len(sizes))}
+    probs = rs.rand(len(groups)).astype(np.float32)
+    probs[rs.rand(len(groups)) < 0.4] = 0.25           # ties: the sort must stay stable
+    for kp, kn in [(1, 30), (100, 5000)]:
+        got = _run_topk(probs, groups, labels, kp, kn, dev)
+        ref = _sample_reference(probs, groups, labels, kp, kn)
+        assert got.tolist() == ref.tolist()
+    offs = np.r_[0, np.cumsum(sizes)].astype(np.int64)
+    order = K.segmented_order(torch.from_numpy(probs).to(dev), torch.from_numpy(offs).to(dev), int(sizes.max()))
+    torch.cuda.synchronize()
+    assert order.cpu().numpy().tolist() == np.lexsort((probs, groups)).tolist()
+
+
 def test_topk_single_group_wraps(dev):
     # one bag of 64 tiles: (i+k) % T always lands in the same group -> nothing selected
     probs = np.random.RandomState(4).rand(64).astype(np.float32)
