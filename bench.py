@@ -73,39 +73,34 @@ def conv_bytes(kind, g, es):
 
 
 def kernel_name(kind, g, dtype):
-    """Name of the kernel instantiation the C dispatcher picks for this launch (mirrors conv_igemm.hip)."""
-    dt = "bf16" if dtype == torch.bfloat16 else "f32"
-    if kind == "wgrad":
-        bm = 128 if g["K"] > 64 else 64
-        if dt == "bf16":      # LDS-DMA kernel: <BM, ring stages, PLAIN (1x1 / stride 1 / no padding), pixels per stage>
-            plain = g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0
-            return f"wgrad_dma_kernel<{bm}, 3, {'true' if plain else 'false'}, 32>"
-        return f"wgrad_kernel<{dt},{bm},128,false>"
-    if kind == "fwd":
-        M, nout, suffix = g["N"] * g["P"] * g["Q"], g["K"], ""
-    else:
-        M, nout, suffix = g["N"] * g["H"] * g["W"], g["C"], ""
-        if g["stride"] > 1:                        # one stride-1 launch per destination parity class
-            M = M // (g["stride"] ** 2)
-            suffix = f" x{g['stride'] ** 2} parity classes"       # one launch covering the stride^2 destination parity classes
-    bm, bn = K.igemm_tile(M, nout)
-    mode = 0 if (g["R"] == 1 and g["S"] == 1 and g["stride"] == 1 and g["pad"] == 0) else 1
-    # epilogue-operand prefetch variant: bf16, more than one 64-element K-step, a residual/add/mask operand, identity destination
-    contracted = (g["C"] if kind == "fwd" else g["K"]) * g["R"] * g["S"]
-    pf = dt == "bf16" and contracted > 64 and g["extra"] > 0 and not suffix
-    # scalar K walk (UNI): every 1x1/s1 launch; tap-walking launches whose tap is wave-uniform (contracted channels % 64 == 0 in
-    # bf16, % 32 in fp32) with at most 32 taps -- the paired stem (8 channels per tap) and 7x7 kernels are not
-    cc = g["C"] if kind == "fwd" else g["K"]
-    per_step = 64 if dt == "bf16" else 32
-    taps = g["R"] * g["S"] if not suffix else 4
-    uni = mode == 0 or (cc % per_step == 0 and taps <= 32 and not (g["R"] == 7 and g["C"] == 8))
-    return f"igemm_dma_kernel<{dt},{bm},{bn},{mode},{'true' if pf else 'false'},{'true' if uni else 'false'}>{suffix}"
+    """Name of the kernel instantiation that ran: reported by the library itself (cs_last_conv_variant, recorded per launch by
+    kernels._timed), never re-derived here -- it is the name rocprofv3 prints for the same launch (tools/check_bench_vs_profile.py)."""
+    return g.get("variant") or "unknown"
+
+
+def _traffic_for(name, by_per_launch):
+    """HBM bytes per launch from the committed PMC passes (tools/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs,
+    gfx950-corrected), newest round first; None when the kernel was not sampled."""
+    for fn in ("round2_traffic.json", "round1_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(tpath):
+            continue
+        try:
+            entry = json.load(open(tpath))["kernels"].get(name)
+        except (ValueError, KeyError):
+            entry = None
+        if entry:
+            return {"hbm_bytes_per_launch": entry["hbm_bytes_per_launch"], "read": entry["read_bytes_per_launch"],
+                    "write": entry["write_bytes_per_launch"], "vs_algorithmic": round(entry["hbm_bytes_per_launch"] / by_per_launch, 2),
+                    "source": f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"}
+    return None
 
 
 def roofline_from(records, steps, dtype):
-    """Per-launch HIP-event times -> roofline of the dominant kernel instantiation (largest share of conv time).
-    Its bound is decided by its aggregate arithmetic intensity against the machine balance: HBM-bound kernels are priced in
-    algorithmic GB/s against the 8 TB/s spec, MFMA-bound ones in TFLOP/s against the dense bf16 peak."""
+    """Per-launch HIP-event times -> roofline of the dominant kernel instantiation (largest share of conv time) plus the dominant
+    MFMA-bound and the dominant HBM-bound one.  A kernel's bound is decided by its aggregate arithmetic intensity against the
+    machine balance: HBM-bound kernels are priced in algorithmic GB/s against the 8 TB/s spec, MFMA-bound ones in TFLOP/s
+    against the dense bf16 peak."""
     es = 2 if dtype == torch.bfloat16 else 4
     per_kernel, per_family = {}, {}
     for kind, g, dt, ms in records:
@@ -126,35 +121,32 @@ def roofline_from(records, steps, dtype):
         if per_step:
             out.update(ms_per_step=round(v[1] / steps, 3), launches_per_step=v[2] // steps)
         else:
-            out.update(avg_ms=round(v[1] / v[2], 4), launches=v[2])
+            out.update(avg_ms=round(v[1] / v[2], 4), launches=v[2], launches_per_step=round(v[2] / steps, 2), ms_per_step=round(v[1] / steps, 3))
         return out
 
-    dom = max(per_kernel, key=lambda k: per_kernel[k][1])
-    fl, ms, n, by = per_kernel[dom]
-    if fl / by < balance:
-        achieved, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-    else:
-        achieved, peak, unit, bound = fl / (ms * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")          # separate PMC passes, tools/collect_traffic.py
-    if os.path.exists(tpath):
-        try:
-            entry = json.load(open(tpath))["kernels"].get(dom.split(" x")[0])
-            if entry:
-                # the timed kernel mix may differ slightly from the sampled one; this is the per-launch average of the PMC run
-                traffic = {"hbm_bytes_per_launch": entry["hbm_bytes_per_launch"], "read": entry["read_bytes_per_launch"],
-                           "write": entry["write_bytes_per_launch"], "vs_algorithmic": round(entry["hbm_bytes_per_launch"] / (by / n), 2),
-                           "source": "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"}
-        except (ValueError, KeyError):
-            traffic = None
+    def entry(name):
+        fl, ms, n, by = per_kernel[name]
+        if fl / by < balance:
+            achieved, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        else:
+            achieved, peak, unit, bound = fl / (ms * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
+        return {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+                "traffic": _traffic_for(name, by / n), "kernel": name, "avg_launch_ms": round(ms / n, 4), "launches": n,
+                "share_of_conv_time": round(ms / sum(v[1] for v in per_kernel.values()), 4),
+                "algorithmic_per_launch": {"gflop": round(fl / n / 1e9, 3), "mbytes": round(by / n / 1e6, 2), "flop_per_byte": round(fl / by, 1)}}
+
+    by_time = sorted(per_kernel, key=lambda k: -per_kernel[k][1])
+    out = entry(by_time[0])
+    mf = [k for k in by_time if per_kernel[k][0] / per_kernel[k][3] >= balance]
+    hb = [k for k in by_time if per_kernel[k][0] / per_kernel[k][3] < balance]
+    out["dominant_mfma_bound"] = entry(mf[0]) if mf else None
+    out["dominant_hbm_bound"] = entry(hb[0]) if hb else None
     three = [v for k, v in per_family.items() if k.startswith("3x3")]
     t3 = sum(v[0] for v in three) / (sum(v[1] for v in three) * 1e-3) / 1e12 if three else None
-    return {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-            "traffic": traffic, "kernel": dom, "avg_launch_ms": round(ms / n, 4), "launches": n,
-            "algorithmic_per_launch": {"gflop": round(fl / n / 1e9, 3), "mbytes": round(by / n / 1e6, 2), "flop_per_byte": round(fl / by, 1)},
-            "conv3x3_family_tflops": round(t3, 2) if t3 else None, "conv3x3_family_frac_of_mfma_peak": round(t3 / peak_tf, 4) if t3 else None,
-            "by_kernel": {k: row(v) for k, v in sorted(per_kernel.items())},
-            "by_family": {k: row(v, True) for k, v in sorted(per_family.items())}}
+    out.update({"conv3x3_family_tflops": round(t3, 2) if t3 else None, "conv3x3_family_frac_of_mfma_peak": round(t3 / peak_tf, 4) if t3 else None,
+                "by_kernel": {k: row(v) for k, v in sorted(per_kernel.items())},
+                "by_family": {k: row(v, True) for k, v in sorted(per_family.items())}})
+    return out
 
 
 def per_layer_table(records, steps, dtype):
@@ -174,18 +166,46 @@ def per_layer_table(records, steps, dtype):
     return "\n".join(out)
 
 
-def cpu_baseline(sample_tiles=8, steps=2):
-    """The oracle (torch CPU fp32 NCHW, proven equal to the reference in tests/golden/make_golden.py)
-    on the same step definition, bounded sample."""
-    from oracle import cellseg_oracle as orc
+def _host_cpu():
+    """(model string, physical cores usable by this process) from lscpu / the affinity mask."""
+    model, cores_per_socket, sockets, threads_per_core = "unknown", None, None, 1
+    try:
+        import subprocess
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                model = v
+            elif k == "Core(s) per socket":
+                cores_per_socket = int(v)
+            elif k == "Socket(s)":
+                sockets = int(v)
+            elif k == "Thread(s) per core":
+                threads_per_core = max(1, int(v))
+    except Exception:  # noqa: BLE001
+        pass
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, int(os.environ.get("CELLSEG_CPU_THREADS", "16"))))   # a 1-GPU box share is 16 cores
+    physical = cores_per_socket * sockets if cores_per_socket and sockets else max(1, avail // threads_per_core)
+    return model, max(1, min(physical, max(1, avail // threads_per_core) if avail < physical * threads_per_core else physical))
+
+
+def cpu_baseline(micro=16, accum=4, steps=3):
+    """The oracle (torch CPU fp32 NCHW, proven equal to the reference in tests/golden/make_golden.py) on the same step definition
+    and the same bag of 64 tiles as the GPU (N = 64 as 16 x 4 -- four micro-batches accumulate into one
+    optimizer step; with BatchNorm frozen the gradients are identical to one batch of 64), 1 warm-up micro-batch + `steps` timed
+    steps, all physical cores of the box this process may use."""
+    from oracle import cellseg_oracle as orc
+    model_name, cores = _host_cpu()
+    if os.environ.get("CELLSEG_CPU_THREADS"):
+        cores = max(1, int(os.environ["CELLSEG_CPU_THREADS"]))
     torch.set_num_threads(cores)
-    x = synth.normalise(synth.ihc_tiles(sample_tiles, SIZE, 1234))
-    labels = torch.tensor([(i * 7 + 1) % 2 for i in range(sample_tiles)])
+    n = micro * accum
+    base = synth.normalise(synth.ihc_tiles(8, SIZE, 1234))
+    x = base.repeat(n // 8, 1, 1, 1).contiguous()
+    labels = torch.tensor([(i * 7 + 1) % 2 for i in range(n)])
     sd = orc.empty_state_dict(ARCH)
     synth.fill_state_dict(sd)
     params = []
@@ -194,18 +214,19 @@ def cpu_baseline(sample_tiles=8, steps=2):
             v.requires_grad_()
             params.append(v)
     opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4)
+    (orc.tile_step_loss(sd, x[:micro], labels[:micro], ARCH)).backward()        # warm-up (allocator, oneDNN primitives)
     times = []
-    for it in range(steps + 1):
+    for it in range(steps):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = orc.tile_step_loss(sd, x, labels, ARCH)
-        loss.backward()
+        for a in range(accum):
+            sl = slice(a * micro, (a + 1) * micro)
+            (orc.tile_step_loss(sd, x[sl], labels[sl], ARCH) * (micro / n)).backward()
         opt.step()
-        if it > 0:
-            times.append(time.perf_counter() - t0)
+        times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    return {"value": round(sample_tiles / t, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_tiles} tiles x {steps} timed steps (1 warm-up), ResNet-50 tile fwd+bwd+Adam fp32, median",
+    return {"value": round(n / t, 3), "unit": "tiles/s", "cores": cores, "kind": "port", "cpu_model": model_name,
+            "sample": f"bag of {n} tiles as {accum} x {micro}, {steps} timed steps (1 warm-up micro-batch), ResNet-50 tile fwd+bwd+Adam fp32, median",
             "s_per_step": round(t, 3)}
 
 

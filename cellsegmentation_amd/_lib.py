@@ -15,7 +15,7 @@ CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU, CS_ACT_SIGMOID = 0, 1, 2, 3
 
 
 class CsConvGeom(Structure):
-    _fields_ = [(n, c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "P", "Q")]
+    _fields_ = [(n, c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "P", "Q", "groups")]
 
 
 class CsStageDesc(Structure):
@@ -58,7 +58,6 @@ _SIGNATURES = {
     "cs_wgrad_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "cs_conv2d_wgrad_splits": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_weight_prep_grouped": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "cs_conv2d_next_is_grouped": (c_int, []),
     "cs_conv2d_wgrad_batched_splits": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_conv2d_wgrad_batched": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, c_int, _P]),
     "cs_wgrad_finalize_batched": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

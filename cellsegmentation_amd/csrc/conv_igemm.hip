@@ -925,7 +925,6 @@ void note_variant(const char* fmt, ...) {
     cs_set_variant_(buf);
 }
 
-thread_local int g_next_slab = 0;   // set by cs_conv2d_next_is_grouped() for exactly one following conv call of this thread
 int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
                             // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
 const bool g_merge_classes = [] { const char* e = getenv("CELLSEG_NO_MERGE"); return !(e && atoi(e)); }();   // A/B experiments only
@@ -1100,9 +1099,6 @@ int check_geom(const CsConvGeom* g, int dtype) {
 }  // namespace
 
 extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_out); }
-/* The next cs_conv2d_fwd / _dgrad / _wgrad call issued by this thread treats the convolution as GROUPED
- * (groups = C / channels_per_group, C == K, C % 64 == 0) in slab-dense form; see cs_weight_prep_grouped. */
-extern "C" int cs_conv2d_next_is_grouped(void) { g_next_slab = 1; return CS_OK; }
 extern "C" int cs_set_igemm_path(int path) {
     // 0 = LDS-DMA (default), 1 = register-staged everywhere, 3 = LDS-DMA + persistent streaming kernel for short-K 1x1
     const int old = g_igemm_path == 1 ? 1 : (g_stream_enabled ? 3 : 0);
@@ -1135,8 +1131,7 @@ extern "C" int cs_conv2d_fwd_bits(const CsConvGeom* g, int dtype, const void* x,
 static int conv2d_fwd_impl(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
                            const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
                            unsigned char* relu_bits, void* stream) {
-    const int slab = g_next_slab;
-    g_next_slab = 0;
+    const int slab = (g && g->groups > 1) ? 1 : 0;
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
     if (slab) CS_CHECK_ARG(g->C % 64 == 0 && g->K == g->C, "grouped conv: width must be a multiple of 64 and C == K");
@@ -1245,8 +1240,7 @@ extern "C" int cs_conv2d_dgrad_bits(const CsConvGeom* g, int dtype, const void* 
 
 static int conv2d_dgrad_impl(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                              const void* mask, const unsigned char* mask_bits, void* dx, float* colsum, void* workspace, void* stream) {
-    const int slab = g_next_slab;
-    g_next_slab = 0;
+    const int slab = (g && g->groups > 1) ? 1 : 0;
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
     if (slab) CS_CHECK_ARG(g->C % 64 == 0 && g->K == g->C, "grouped conv: width must be a multiple of 64 and C == K");
@@ -1926,8 +1920,7 @@ extern "C" int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const voi
 
 extern "C" int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                                int use_tr_read, void* stream) {
-    const int slab = g_next_slab;
-    g_next_slab = 0;
+    const int slab = (g && g->groups > 1) ? 1 : 0;
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
     if (slab) CS_CHECK_ARG(g->C % 64 == 0 && g->K == g->C, "grouped conv: width must be a multiple of 64 and C == K");

@@ -671,6 +671,7 @@ const bool g_v2_off = [] { const char* e = getenv("CELLSEG_NO_V2"); return e && 
 
 bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
+    if (g->groups > 1) return false;
     if (g->R != 3 || g->S != 3 || g->stride != 1 || g->pad < 0 || g->pad > 2) return false;
     const int SC = dgrad ? g->K : g->C, NOUT = dgrad ? g->C : g->K;
     const int SH = dgrad ? g->P : g->H, SW = dgrad ? g->Q : g->W;
@@ -726,6 +727,7 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
 
 bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
+    if (g->groups > 1) return false;
     if (g->R != 1 || g->S != 1 || g->pad != 0 || g->stride < 1) return false;
     if (dgrad && g->stride != 1) return false;
     const int SC = dgrad ? g->K : g->C, NOUT = dgrad ? g->C : g->K;

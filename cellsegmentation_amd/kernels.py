@@ -46,10 +46,10 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
-def make_geom(N, H, W, C, K, R, S, stride, pad):
+def make_geom(N, H, W, C, K, R, S, stride, pad, groups=1):
     P = (H + 2 * pad - R) // stride + 1
     Q = (W + 2 * pad - S) // stride + 1
-    return CsConvGeom(N, H, W, C, K, R, S, stride, pad, P, Q)
+    return CsConvGeom(N, H, W, C, K, R, S, stride, pad, P, Q, groups)
 
 
 # ---------------------------------------------------------------- layout
@@ -229,9 +229,14 @@ def wgrad_finalize_grouped(dw_slab, w, scale, rstd, mean, gsum, dw, dgamma=None,
                                                      _p(dgamma), _p(dbeta), _p(dot), _stream()), "wgrad_finalize_grouped")
 
 
-def _mark_grouped(grouped):
-    if grouped:
-        _lib.load().cs_conv2d_next_is_grouped()
+def _grouped_geom(geom, grouped):
+    """The geometry the C side sees: `groups > 1` selects the slab-dense grouped kernels (an explicit field of CsConvGeom; the
+    library keeps no per-thread state between calls)."""
+    if not grouped or geom.groups > 1:
+        return geom
+    g = CsConvGeom.from_buffer_copy(geom)
+    g.groups = max(2, geom.C // 64 if geom.C >= 128 else 2)      # any value > 1: the staged weights carry the block structure
+    return g
 
 
 def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_NONE, stats=None, out=None, grouped=False,
@@ -240,7 +245,7 @@ def conv_fwd(geom, x, w_khwc, scale=None, shift=None, residual=None, act=CS_ACT_
     ReLU mask a later data gradient needs -> (y, bits)."""
     y = out if out is not None else torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x.dtype, device=x.device)
     lib = _lib.load()
-    _mark_grouped(grouped)
+    geom = _grouped_geom(geom, grouped)
     if want_bits:
         if stats is not None:
             raise ValueError("conv_fwd: want_bits and stats are separate entry points")
@@ -400,7 +405,7 @@ def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False
     instead of `mask`."""
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
-    _mark_grouped(grouped)
+    geom = _grouped_geom(geom, grouped)
     defer = defer_colsum and geom.stride == 1 and not grouped
     ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if (colsum is not None or defer) else None
     if mask_bits is not None:
@@ -432,7 +437,7 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
     if dw_raw.dim() != 5 or dw_raw.shape[0] != wgrad_splits(geom, grouped):
         raise ValueError("conv_wgrad: dw_raw must come from new_wgrad_buffer(geom, ...)")
     lib = _lib.load()
-    _mark_grouped(grouped)
+    geom = _grouped_geom(geom, grouped)
     _lib.check(_timed("wgrad", geom, x.dtype, lambda: lib.cs_conv2d_wgrad(
         ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw_raw), 1 if use_tr_read else 0, _stream())), "conv2d_wgrad")
     return dw_raw

@@ -45,6 +45,7 @@ typedef struct CsConvGeom {
     int32_t R, S;       /* kernel height, width */
     int32_t stride, pad;
     int32_t P, Q;       /* output height, width */
+    int32_t groups;     /* 0 or 1: dense; > 1: grouped convolution in slab-dense form (ResNeXt, see cs_weight_prep_grouped) */
 } CsConvGeom;
 
 /* ---- layout / precision changes at the module boundary ------------------------------------- */
@@ -187,12 +188,11 @@ int cs_wgrad_finalize(const float* dw_khwc, int nsplit, int Kp, const float* w, 
  * C == K, C % 64 == 0, Cg = C/groups divides 64.  Each 64-channel destination tile contracts only over its
  * own 64 source channels with weights that are block-diagonal inside the slab:
  *   cs_weight_prep_grouped: w[K][Cg][R][S] fp32 -> w_khwc[K][R][S][64], w_chwk[C][R][S][64]
- *   cs_conv2d_next_is_grouped(): marks the NEXT cs_conv2d_fwd/_dgrad/_wgrad call of this thread as grouped
+ *   cs_conv2d_fwd / _dgrad / _wgrad with CsConvGeom.groups > 1 take these operands
  *     (same signatures; dw buffer of wgrad is [K][R][S][64] fp32)
  *   cs_wgrad_finalize_grouped: picks the group diagonal out of the slab gradient -> dw[K][Cg][R][S] (+BN-eval grads) */
 int cs_weight_prep_grouped(const float* w, const float* scale, int dtype, int K, int Cg, int R, int S, void* w_khwc,
                            void* w_chwk, void* stream);
-int cs_conv2d_next_is_grouped(void);
 int cs_wgrad_finalize_grouped(const float* dw_slab, int nsplit, const float* w, const float* scale, const float* rstd,
                               const float* mean, const float* gsum, int K, int Cg, int R, int S, float* dw, float* dgamma,
                               float* dbeta, float* dot_ws, void* stream);

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""bench.py's roofline must be reproducible from the committed rocprofv3 summary of the same command:
+
+    python tools/check_bench_vs_profile.py <bench.json (one JSON line)> <*_kernel_stats.csv> <steps in the profiled run, warm-up included>
+
+Fails (exit 1) when a `roofline.by_kernel` name is absent from the rocprofv3 table, when launch counts per step differ, when
+average durations disagree by more than 15 %, or when `roofline.kernel` is not the top conv-family row of the profile."""
+import csv
+import json
+import re
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_profile import demangle  # noqa: E402
+
+
+def norm(name):
+    return re.sub(r"\s+", "", name)
+
+
+def main():
+    bench_path, csv_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    line = [l for l in open(bench_path).read().splitlines() if l.startswith("{")][-1]
+    roof = json.loads(line)["roofline"]
+    prof = {}
+    for r in csv.DictReader(open(csv_path)):
+        k = norm(demangle(r["Name"]))
+        e = prof.setdefault(k, [0, 0.0])
+        e[0] += int(r["Calls"]); e[1] += float(r["TotalDurationNs"])
+    bad = []
+    for name, row in roof["by_kernel"].items():
+        k = norm(name)
+        if k not in prof:
+            bad.append(f"{name}: not in the rocprofv3 table")
+            continue
+        calls, tot = prof[k]
+        if abs(calls / steps - row["launches_per_step"]) > 0.26:
+            bad.append(f"{name}: {calls / steps:.2f} launches/step in the profile vs {row['launches_per_step']} in bench.py")
+        avg_ms = tot / calls / 1e6
+        if abs(avg_ms - row["avg_ms"]) > 0.15 * max(avg_ms, row["avg_ms"]):
+            bad.append(f"{name}: average {avg_ms * 1e3:.1f} us in the profile vs {row['avg_ms'] * 1e3:.1f} us by HIP events")
+    conv = {k: v for k, v in prof.items() if k.startswith(("igemm", "wgrad_dma", "wgrad_kernel", "conv2_"))}
+    top = max(conv, key=lambda k: conv[k][1]) if conv else None
+    if top != norm(roof["kernel"]):
+        bad.append(f"roofline.kernel = {roof['kernel']} but the top conv-family row of the profile is {top}")
+    for b in bad:
+        print("MISMATCH:", b)
+    print(f"checked {len(roof['by_kernel'])} kernels against {csv_path}: {'FAIL' if bad else 'OK'}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

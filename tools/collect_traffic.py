@@ -24,7 +24,7 @@ def per_kernel(path, counter):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(os.path.join(path, "p_counter_collection.csv"))):
         if r["Counter_Name"] == counter:
-            e = agg[demangle(r["Kernel_Name"])]
+            e = agg[demangle(r["Kernel_Name"]).replace(' ', '')]
             e[0] += float(r["Counter_Value"])
             e[1] += 1
     return {k: v[0] / v[1] for k, v in agg.items()}, {k: v[1] for k, v in agg.items()}
@@ -36,7 +36,7 @@ def main():
     w, _ = per_kernel(write_dir, "WRITE_SIZE")
     res = {}
     for k in f:
-        if not (k.startswith("igemm") or k.startswith("wgrad")):
+        if not k.startswith(("igemm", "wgrad", "conv2_")):
             continue
         rd = f[k] * 1024 * 2.0          # gfx950: FETCH_SIZE = 1/2 of a wide coalesced read
         wr = w.get(k, 0.0) * 1024
