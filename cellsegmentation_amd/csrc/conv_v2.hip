@@ -108,16 +108,17 @@ __device__ __forceinline__ void own_registers() {
 }
 template <int REG> __device__ __forceinline__ void vzero() { asm volatile("v_mov_b32 v[%c0], 0" ::"i"(REG)); }
 template <int... Rs> __device__ __forceinline__ void vzero_seq(std::integer_sequence<int, Rs...>) { (vzero<R_ACC + Rs>(), ...); }
+template <int BASE, int... Rs> __device__ __forceinline__ void vzero_at(std::integer_sequence<int, Rs...>) { (vzero<BASE + Rs>(), ...); }
 
-template <int J>
+template <int J, int RB = R_B>
 __device__ __forceinline__ void bload4(const i32x4& rsrc, unsigned voff, unsigned soff) {
     // the four 1 KiB weight fragments of one tap-step (64 contraction channels) of this wave's 32 output channels
     asm volatile("buffer_load_dwordx4 v[%c3:%c4], %0, %1, %2 offen\n\t"
                  "buffer_load_dwordx4 v[%c5:%c6], %0, %1, %2 offen offset:1024\n\t"
                  "buffer_load_dwordx4 v[%c7:%c8], %0, %1, %2 offen offset:2048\n\t"
                  "buffer_load_dwordx4 v[%c9:%c10], %0, %1, %2 offen offset:3072"
-                 ::"v"(voff), "s"(rsrc), "s"(soff), "i"(R_B + 16 * J), "i"(R_B + 16 * J + 3), "i"(R_B + 16 * J + 4), "i"(R_B + 16 * J + 7),
-                 "i"(R_B + 16 * J + 8), "i"(R_B + 16 * J + 11), "i"(R_B + 16 * J + 12), "i"(R_B + 16 * J + 15));
+                 ::"v"(voff), "s"(rsrc), "s"(soff), "i"(RB + 16 * J), "i"(RB + 16 * J + 3), "i"(RB + 16 * J + 4), "i"(RB + 16 * J + 7),
+                 "i"(RB + 16 * J + 8), "i"(RB + 16 * J + 11), "i"(RB + 16 * J + 12), "i"(RB + 16 * J + 15));
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 template <int DST, int ADDR, unsigned OFF> __device__ __forceinline__ void lds_rd() {
@@ -139,7 +140,7 @@ template <int ACC, int B, int A> __device__ __forceinline__ f32x16 mfma_out() {
     return d;
 }
 // operand-row addresses of one tap for the 4 pixel tiles -> address set S (see row_addr; hhb = chunk-column bit of the lane half)
-template <int S>
+template <int S, int RAD = R_AD, int RTMP = R_TMP>
 __device__ __forceinline__ void addr4(unsigned q0, unsigned q1, unsigned q2, unsigned q3, unsigned sh, unsigned hhb, unsigned cf0) {
 #define CS_ADDR1(Q, A)                                             \
     "v_add_lshl_u32 v[%c[" A "]], %[" Q "], %[sh], 4\n\t"           \
@@ -148,7 +149,7 @@ __device__ __forceinline__ void addr4(unsigned q0, unsigned q1, unsigned q2, uns
     "v_lshl_or_b32 v[%c[" A "]], v[%c[t]], 3, v[%c[" A "]]\n\t"
     asm volatile(CS_ADDR1("q0", "a0") CS_ADDR1("q1", "a1") CS_ADDR1("q2", "a2") CS_ADDR1("q3", "a3")
                  ::[q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3), [sh] "s"(sh), [hhb] "v"(hhb), [cf0] "s"(cf0),
-                 [a0] "i"(R_AD + 4 * S), [a1] "i"(R_AD + 4 * S + 1), [a2] "i"(R_AD + 4 * S + 2), [a3] "i"(R_AD + 4 * S + 3), [t] "i"(R_TMP));
+                 [a0] "i"(RAD + 4 * S), [a1] "i"(RAD + 4 * S + 1), [a2] "i"(RAD + 4 * S + 2), [a3] "i"(RAD + 4 * S + 3), [t] "i"(RTMP));
 #undef CS_ADDR1
 }
 // one accumulator register into a compiler value (after the loop)
@@ -234,19 +235,15 @@ __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     a = r[0];
     b = r[1];
 }
-__device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
-    const unsigned wds[4] = {o.x, o.y, o.z, o.w};
-    unsigned mb = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        mb |= ((int)(wds[i] << 16) > 0 ? 1u : 0u) << (2 * i);
-        mb |= ((int)(wds[i] & 0xffff0000u) > 0 ? 1u : 0u) << (2 * i + 1);
-    }
-    return mb;
-}
 
 // ---- epilogue of one wave: TM pixel tiles (32 pixels each, pixel on the lane) x 32 channels (on the register index) ----
 // accumulator tile i, register r: pixel m0w + 32*i + (lane & 31), channel n_w + 8*(r >> 2) + 4*(lane >> 5) + (r & 3)
+// * global memory is touched in ROW arrangement only: lane L handles, for q = 0,1, the 16-byte piece (L & 3) of pixel
+//   16q + (L >> 2) of the tile -- four consecutive lanes cover the wave's 64 contiguous bytes of one pixel.  Stamped, the
+//   accumulator arrangement (one lane = one pixel, 64 lanes = 64 rows 2*NOUT bytes apart) cost 160-250 cycles PER INSTRUCTION
+//   for its 16-byte-per-row requests and made the 1x1 layers address-rate-bound at ~3.8 TB/s.  The exchange between the two
+//   arrangements goes through a wave-private 32 x 80-byte LDS scratch (80: the 16-byte writes of 8 consecutive pixel lanes fall
+//   into distinct banks), 2 ds_write_b128 + 2 ds_read_b128 per direction, no workgroup barrier;
 // * its global operands are fetched BEFORE the main loop (prefetch()): stamped, the epilogue spent ~2/3 of its 5-7 k cycles
 //   waiting for the shift vector and for one residual / mask load per tile, each a full memory latency with nothing in flight;
 // * every global access is a raw-buffer access with a 32-bit offset: rows past the end carry an out-of-range offset and are
@@ -256,29 +253,78 @@ __device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
 // state is small -- the multi-chunk halo kernels would spill, and their layers have no such operand in practice).
 // DG: data-gradient flavour (add operand, mask bits in, column sums out) instead of the forward one (shift, residual, ReLU,
 // sign bits out): two instantiations instead of runtime branches keep the epilogue's register footprint under the cap.
+constexpr unsigned EPI_ROW = 80u, EPI_WAVE = 32u * EPI_ROW, EPI_LDS = 4u * EPI_WAVE;
+using lds_u32x4 = __attribute__((address_space(3))) u32x4;
+__device__ __forceinline__ void lds_put(unsigned a, const uint4& v) { *(lds_u32x4*)(unsigned long)(a) = __builtin_bit_cast(u32x4, v); }
+__device__ __forceinline__ uint4 lds_get(unsigned a) { return __builtin_bit_cast(uint4, *(lds_u32x4*)(unsigned long)(a)); }
+template <int CTRL> __device__ __forceinline__ unsigned quad(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+// bit k of the result = (bf16 element k of the 16 bytes is > 0); both halves of a dword are tested at once: bit 15 of
+// ((h & 0x7fff) + 0x7fff) says "magnitude non-zero", and-not h clears it for negative values
+__device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
+    const unsigned wds[4] = {o.x, o.y, o.z, o.w};
+    unsigned t = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a = ((wds[i] & 0x7fff7fffu) + 0x7fff7fffu) & ~wds[i];
+        t |= ((a >> 15) & 0x10001u) << (2 * i);
+    }
+    return (t | (t >> 15)) & 0xffu;
+}
+// the 16 bytes with element k kept where bit k of b is set
+__device__ __forceinline__ uint4 keep_bits8(const uint4& o, unsigned b) {
+    unsigned wds[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned m = (b >> (2 * i));
+        wds[i] &= (m & 1u) * 0xffffu + (m & 2u) * 0x7fff8000u;
+    }
+    return make_uint4(wds[0], wds[1], wds[2], wds[3]);
+}
+
 template <int TM, bool PRE_RES, bool DG> struct Epilogue {
     const C2Params& p;
     unsigned m0w, slab_row;
     int n_w;
     bool alive;
+    unsigned scr;              // LDS byte address of this wave's exchange scratch (EPI_WAVE bytes)
     float sh[16];
-    uint4 ra[TM], rb[TM];      // residual / add: the lane's two 16-byte pieces per tile, in STORED arrangement
-    unsigned mb[TM];           // mask bits of the wave's 32 channels per tile
-    float s1[16];
+    uint4 rr[TM][2];           // residual / add in row arrangement
+    unsigned mb[TM];           // mask words: lanes with piece 0 / 1 hold the dword of pixel q = 0 / 1
+    float s1[8];
+#ifdef CS_DEBUG_V2
+    unsigned long long e_acc[4] = {0, 0, 0, 0}, e_t = 0;
+#define CS_ETICK(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); e_acc[k] += t_ - e_t; e_t = t_; } while (0)
+#define CS_ESTART() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e_t))
+#else
+#define CS_ETICK(k)
+#define CS_ESTART()
+#endif
     __amdgpu_buffer_rsrc_t r_dst, r_res, r_bin, r_bout;
 
-    __device__ __forceinline__ Epilogue(const C2Params& p_, unsigned m0w_, int n_w_, unsigned slab_row_, bool alive_)
-        : p(p_), m0w(m0w_), slab_row(slab_row_), n_w(n_w_), alive(alive_) {}
+    __device__ __forceinline__ Epilogue(const C2Params& p_, unsigned m0w_, int n_w_, unsigned slab_row_, bool alive_, unsigned scr_)
+        : p(p_), m0w(m0w_), slab_row(slab_row_), n_w(n_w_), alive(alive_), scr(scr_) {}
 
-    __device__ __forceinline__ unsigned row_off(int i) const {      // byte offset of (pixel of tile i, channel n_w + 8 * hh) in a [M][NOUT] bf16 tensor
+    // row arrangement: byte offset of (pixel 16q + (lane >> 2) of tile i, the lane's piece) in a [M][NOUT] bf16 tensor
+    __device__ __forceinline__ unsigned row_off_at(unsigned base, int i, int q) const {
         const int lane = threadIdx.x & 63;
-        const unsigned m = m0w + 32u * i + (unsigned)(lane & 31);
-        return (m < p.M && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w + ((lane >> 5) ? 8u : 0u)) * 2u : OOB;
+        const unsigned m = base + 32u * i + 16u * q + (unsigned)(lane >> 2);
+        return (m < p.M && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w + 8u * (unsigned)(lane & 3)) * 2u : OOB;
     }
-    __device__ __forceinline__ unsigned bit_off(int i) const {      // byte offset of the pixel's dword of 32 channel bits
+    // the dword of 32 channel bits of pixel 16q + (lane >> 2), q = the lane's piece (pieces 2 and 3: none)
+    __device__ __forceinline__ unsigned bit_off_at(unsigned base, int i) const {
         const int lane = threadIdx.x & 63;
-        const unsigned m = m0w + 32u * i + (unsigned)(lane & 31);
-        return (m < p.M && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w) >> 3 : OOB;
+        const unsigned m = base + 32u * i + 16u * (unsigned)(lane & 1) + (unsigned)(lane >> 2);
+        return (m < p.M && alive && !(lane & 2)) ? (m * (unsigned)p.NOUT + (unsigned)n_w) >> 3 : OOB;
+    }
+    __device__ __forceinline__ unsigned row_lds(int q) const {       // row arrangement: the lane's slot in the scratch
+        const int lane = threadIdx.x & 63;
+        return scr + (unsigned)(16 * q + (lane >> 2)) * EPI_ROW + (unsigned)(lane & 3) * 16u;
+    }
+    __device__ __forceinline__ unsigned acc_lds(int j) const {       // accumulator arrangement: piece 2j + hh of pixel l31
+        const int lane = threadIdx.x & 63;
+        return scr + (unsigned)(lane & 31) * EPI_ROW + (unsigned)(2 * j + (lane >> 5)) * 16u;
     }
 
     __device__ __forceinline__ void prefetch() {
@@ -299,27 +345,32 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
         for (int i = 0; i < TM; ++i) {
             // a NULL operand has a zero-sized buffer: the loads return zeros without touching memory
             if constexpr (PRE_RES) {
-                const unsigned off = row_off(i);
-                ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 0));
-                rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 32, 0));
+                rr[i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, i, 0), 0, 0));
+                rr[i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, i, 1), 0, 0));
             }
-            if constexpr (DG) mb[i] = __builtin_amdgcn_raw_buffer_load_b32(r_bin, bit_off(i), 0, 0);
+            if constexpr (DG) mb[i] = __builtin_amdgcn_raw_buffer_load_b32(r_bin, bit_off_at(m0w, i), 0, 0);
         }
     }
 
     template <int I> __device__ __forceinline__ void operator()(const f32x16& acc) {
         const int lane = threadIdx.x & 63;
-        const int hh = lane >> 5;
+        const unsigned piece = (unsigned)(lane & 3);
+        CS_ESTART();
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = DG ? acc[r] : acc[r] + sh[r];
         if (p.residual) {
-            uint4 xa, xb;
-            if constexpr (PRE_RES) { xa = ra[I]; xb = rb[I]; }
+            uint4 x0, x1;
+            if constexpr (PRE_RES) { x0 = rr[I][0]; x1 = rr[I][1]; }
             else {
-                xa = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off(I), 0, 0));
-                xb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off(I), 32, 0));
+                x0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, I, 0), 0, 0));
+                x1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, I, 1), 0, 0));
             }
+            lds_put(row_lds(0), x0);
+            lds_put(row_lds(1), x1);
+            __builtin_amdgcn_wave_barrier();
+            uint4 xa = lds_get(acc_lds(0)), xb = lds_get(acc_lds(1));
+            __builtin_amdgcn_wave_barrier();
             // stored arrangement -> accumulator arrangement (the swap is an involution)
             swap32(xa.x, xa.z); swap32(xa.y, xa.w);
             swap32(xb.x, xb.z); swap32(xb.y, xb.w);
@@ -336,59 +387,65 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
-        if (DG && p.bits_in) {
-            const unsigned mine = mb[I] >> (4 * hh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = ((mine >> (8 * (r >> 2) + (r & 3))) & 1u) ? v[r] : 0.f;
-        }
         unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        const unsigned off = row_off(I);
-        if constexpr (DG && I == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s1[r] = 0.f;
-        }
-        if (DG && p.slab && off != OOB) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float lo, hi;
-                unpack2(pk[k], lo, hi);            // statistics are those of the STORED values
-                s1[2 * k] += lo; s1[2 * k + 1] += hi;
-            }
-        }
         // groups (0,1) and (2,3): after the swaps lanes 0-31 hold channels 16j .. 16j+7, lanes 32-63 channels 16j+8 .. 16j+15
         swap32(pk[0], pk[2]); swap32(pk[1], pk[3]);
         swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
-        const uint4 oa = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        const uint4 ob = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oa), r_dst, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), r_dst, off, 32, 0);
-        if (!DG && p.bits_out) {
-            // byte j of the pixel's dword = channels 8j .. 8j+7: this lane owns bytes (hh, 2 + hh)
-            unsigned w = (pos_bits8(oa) | (pos_bits8(ob) << 16)) << (8 * hh);
-            unsigned up = 0u;
-            swap32(w, up);                     // lanes 0-31 of `up` <- the upper half's word
-            __builtin_amdgcn_raw_buffer_store_b32(w | up, r_bout, hh ? OOB : bit_off(I), 0, 0);
+        lds_put(acc_lds(0), make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        lds_put(acc_lds(1), make_uint4(pk[4], pk[5], pk[6], pk[7]));
+        __builtin_amdgcn_wave_barrier();
+        uint4 o0 = lds_get(row_lds(0)), o1 = lds_get(row_lds(1));
+        __builtin_amdgcn_wave_barrier();
+        CS_ETICK(0);
+        if constexpr (DG) {
+            if (p.bits_in) {
+                const unsigned w0 = quad<0x00>(mb[I]), w1 = quad<0x55>(mb[I]);       // broadcast lane 0 / lane 1 of the quad
+                o0 = keep_bits8(o0, w0 >> (8u * piece));
+                o1 = keep_bits8(o1, w1 >> (8u * piece));
+            }
+            if constexpr (I == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s1[k] = 0.f;
+            }
+            if (p.slab) {                      // statistics are those of the STORED values; rows past the end are zeros
+                const unsigned ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float lo, hi;
+                    unpack2(ow[k], lo, hi);
+                    s1[2 * (k & 3)] += lo; s1[2 * (k & 3) + 1] += hi;
+                }
+            }
         }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), r_dst, row_off_at(m0w, I, 0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), r_dst, row_off_at(m0w, I, 1), 0, 0);
+        CS_ETICK(1);
+        if (!DG && p.bits_out) {
+            // byte j of a pixel's dword = channels 8j .. 8j+7 = piece j; OR over the quad, then lane (piece q) stores pixel q's dword
+            unsigned w0 = pos_bits8(o0) << (8u * piece), w1 = pos_bits8(o1) << (8u * piece);
+            w0 |= quad<0xb1>(w0); w1 |= quad<0xb1>(w1);       // [1,0,3,2]
+            w0 |= quad<0x4e>(w0); w1 |= quad<0x4e>(w1);       // [2,3,0,1]
+            __builtin_amdgcn_raw_buffer_store_b32((lane & 1) ? w1 : w0, r_bout, bit_off_at(m0w, I), 0, 0);
+        }
+        CS_ETICK(2);
+        CS_ETICK(3);
     }
 
     __device__ __forceinline__ void finish() {
         if (!DG || !p.slab || !alive) return;
         const int lane = threadIdx.x & 63;
-        const int l31 = lane & 31, hh = lane >> 5;
-        // fold the 32 pixel-lanes of each half; lane (l31 == r) keeps channel register r
-        float mine1 = 0.f;
+        // fold the 16 lanes that share a piece; lanes 0-3 keep the 8 channels of piece 0-3
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = s1[r];
+        for (int k = 0; k < 8; ++k) {
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-            if (l31 == r) mine1 = a;
+            for (int off = 32; off >= 4; off >>= 1) s1[k] += __shfl_xor(s1[k], off, 64);
         }
-        if (l31 < 16) {
-            const int ch = n_w + 8 * (l31 >> 2) + 4 * hh + (l31 & 3);
-            p.slab[(size_t)slab_row * 2 * p.NOUT + ch] = mine1;
+        if (lane < 4) {
+            float* dst = p.slab + (size_t)slab_row * 2 * p.NOUT + n_w + 8 * lane;
+            *reinterpret_cast<float4*>(dst) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(s1[4], s1[5], s1[6], s1[7]);
         }
     }
 };
@@ -462,7 +519,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     const unsigned smem_base = lds_off(smem);
 
     static_assert(TM >= 2 && TM <= 4, "the register map of the main loop holds up to 4 pixel tiles per wave");
-    Epilogue<TM, (NBW > 5), DG> epi(p, m0w, n_w, mtile * WM + wm, alive);
+    Epilogue<TM, (NBW > 5), DG> epi(p, m0w, n_w, mtile * WM + wm, alive, 0u);
     epi.prefetch();
     CS_STAMP(4);
     own_registers();
@@ -498,6 +555,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
         wait_vm<(has1 ? 4 : 0) + (has2 ? 4 : 0) + D0 + D1 + D2>();
         const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.Wp + (unsigned)(T % SK);
         const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.Wp + (unsigned)((T + 1) % SK);
+        // the epilogue's exchange scratch: the stage nobody reads or fills during the last chunk (single-stage launches: the
+        // bytes behind the stage)
+        if constexpr (T == NTAP - 1 && !HN) epi.scr = smem_base + NXT_STAGE + (unsigned)wave * EPI_WAVE;
         tap_mfma<TM, CUR, T & 1, CUR_STAGE, CUR_STAGE, T == 0, T != NTAP - 1, false, (T == NTAP - 1 && !HN)>(qb[0], qb[1], qb[2 % TM], qb[3 % TM], sh_cur, sh_next,
                                                                                                           hhb, cf0, epi);
     };
@@ -590,7 +650,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)(NCC * 4096);
     const unsigned smem_base = lds_off(smem);
 
-    Epilogue<TM, true, DG> epi(p, m0w, n_w, mtile * WM + wm, alive);
+    Epilogue<TM, true, DG> epi(p, m0w, n_w, mtile * WM + wm, alive, smem_base + (unsigned)NCC * CHB + (unsigned)wave * EPI_WAVE);
     epi.prefetch();
     CS_STAMP(4);
     own_registers();
@@ -631,6 +691,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
 #endif
 }
 
+
 // ---- weights [ROWS][taps][COLS] bf16 (ROWS = destination channels, COLS = contraction channels, both staged layouts of
 // cs_weight_prep have this shape) -> MFMA-fragment order [row tile 32][chunk 64][tap][k16][lane][8]; flip = taps mirrored
 // (data gradient).  One thread per 16 bytes.
@@ -664,8 +725,22 @@ void magic(unsigned d, unsigned& mg, unsigned& sh) {
 // geometry of the packed-operand launch; cfg: 0 = not served, 1 = 128 px x 128 ch (1x4 waves), 2 = 256 px x 64 ch (2x2 waves)
 struct C2Plan {
     int cfg, nbw, ncc, rows;       // rows = partial column-sum rows
+    int tm;                        // pixel tiles (32 px) per wave: 1 x 4 configuration only
     C2Params p;
 };
+
+// Pixel-tile height of the 1 x 4 halo configuration.  Workgroups do not run in lock-step rounds, so a shorter tile only pays
+// where the whole grid is resident at once (<= 512 workgroups on 256 compute units, two each) and the busiest compute unit's
+// share shrinks: ResNet-50 layer3 (M = 23104, N = 256) is 362 workgroups of 128 px -- 106 compute units hold two -- but 482
+// of 96 px, each 3/4 of the work: measured 34.0 -> 29.3 us forward.  Elsewhere the shorter tile loses: layer2 (722 -> 963
+// workgroups: the same total work plus 241 more prologues, 31.9 -> 33.3 us) and layer4 (200 workgroups of 128 px, one per compute
+// unit; 64-px tiles re-read the 4.7 MB of weights twice as often and run into the L2 -> LDS feed, 33.4 -> 37.9 us).
+int pick_tm(long long M, int n_ntiles) {
+    static const int forced = [] { const char* e = getenv("CELLSEG_TM"); return e ? atoi(e) : 0; }();   // experiments only
+    if (forced >= 2 && forced <= 4) return forced;
+    const long long wg4 = ((M + 127) / 128) * n_ntiles, wg3 = ((M + 95) / 96) * n_ntiles;
+    return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
+}
 
 const bool g_v2_off = [] { const char* e = getenv("CELLSEG_NO_V2"); return e && atoi(e); }();
 
@@ -691,10 +766,13 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
         const long long rows = span + (long long)(g->R - 1) * Wp + (g->S - 1) + 1;
         return (int)((rows + 15) / 16);
     };
-    int cfg = 0, nbw = 0;
+    int cfg = 0, nbw = 0, tm = 4;
     if (NOUT % 128 == 0) {
-        const int nb = (window_blocks(128) + 3) / 4;
-        if (ncc == 1 ? nb <= 8 : nb <= 5) { cfg = 1; nbw = nb < 3 ? 3 : nb; }
+        tm = pick_tm(M, NOUT / 128);
+        for (; tm <= 4; ++tm) {              // a shorter tile has a smaller window; fall back to taller ones only if it somehow does not fit
+            const int nb = (window_blocks(32 * tm) + 3) / 4;
+            if (ncc == 1 ? nb <= 8 : nb <= 5) { cfg = 1; nbw = nb < 3 ? 3 : nb; break; }
+        }
     } else if (NOUT == 64 && ncc == 1) {
         const int nb = (window_blocks(256) + 3) / 4;
         if (nb <= 8) { cfg = 2; nbw = 8; }
@@ -718,13 +796,12 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     const unsigned long long wbytes = (unsigned long long)cs_ceil_div(NOUT, 32) * 32 * g->R * g->S * (unsigned long long)SC * 2ull;
     if (wbytes >= 0x80000000ull) return false;
     p.wpk_bytes = (unsigned)wbytes;
-    const int BM = cfg == 1 ? 128 : 256, BN = cfg == 1 ? 128 : 64;
+    const int BM = cfg == 1 ? 32 * tm : 256, BN = cfg == 1 ? 128 : 64;
     p.n_ntiles = cs_ceil_div(NOUT, BN);
-    pl.cfg = cfg; pl.nbw = nbw; pl.ncc = ncc;
+    pl.cfg = cfg; pl.nbw = nbw; pl.ncc = ncc; pl.tm = cfg == 1 ? tm : 4;
     pl.rows = cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
     return true;
 }
-
 bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
     if (g->groups > 1) return false;
@@ -767,15 +844,32 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     return true;
 }
 
+// dynamic LDS beyond 64 KiB has to be allowed per kernel, once (the table is keyed by the kernel's address; launches of one
+// process come from the threads that own a stream, a benign race re-raises the attribute)
+template <typename F> bool allow_lds(F fn, size_t bytes) {
+    if (bytes <= 65536) return true;
+    static const void* done[64];
+    static int n_done = 0;
+    for (int i = 0; i < n_done; ++i) if (done[i] == reinterpret_cast<const void*>(fn)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) {
+        cs_set_error_("conv2: cannot raise the dynamic LDS limit");
+        return false;
+    }
+    if (n_done < 64) done[n_done++] = reinterpret_cast<const void*>(fn);
+    return true;
+}
+
 template <int NCC, int TM, int WM, int WN, bool DG>
 int launch_gemm_t(const C2Params& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     const unsigned n_mt = (unsigned)cs_ceil_div(p.M, BM);
+    const size_t lds = (size_t)NCC * BM * 128 + EPI_LDS;
     dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
     char name[64];
     snprintf(name, sizeof(name), "conv2_gemm_kernel<%d,%d,%d,%d,%s>", NCC, TM, WM, WN, DG ? "true" : "false");
     cs_set_variant_(name);
-    hipLaunchKernelGGL((conv2_gemm_kernel<NCC, TM, WM, WN, DG>), grid, dim3(256), (size_t)NCC * BM * 128, st, p);
+    if (!allow_lds(conv2_gemm_kernel<NCC, TM, WM, WN, DG>, lds)) return CS_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv2_gemm_kernel<NCC, TM, WM, WN, DG>), grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
@@ -795,24 +889,16 @@ int launch_gemm(const C2Plan& pl, hipStream_t st) {
     return pl.ncc == 3 ? launch_gemm_t<3, 2, 2, 2, DG>(p, st) : launch_gemm_t<4, 2, 2, 2, DG>(p, st);
 }
 
-template <int NBW, bool DG>
+template <int TM, int NBW, bool DG>
 int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
-    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 128);
+    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 32 * TM);
     dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
-    const size_t lds = (size_t)NBW * 8192 * (two_stage ? 2 : 1);
-    auto fn = conv2_halo_kernel<9, 3, 4, 1, 4, NBW, DG>;
-    if (lds > 65536) {
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) {
-                cs_set_error_("conv2: cannot raise the dynamic LDS limit");
-                return CS_ERR_LAUNCH;
-            }
-            raised = true;
-        }
-    }
+    // two stages: the epilogue borrows the idle one; one stage: its exchange scratch sits behind it
+    const size_t lds = two_stage ? (size_t)NBW * 8192 * 2 : (size_t)NBW * 8192 + EPI_LDS;
+    auto fn = conv2_halo_kernel<9, 3, TM, 1, 4, NBW, DG>;
+    if (!allow_lds(fn, lds)) return CS_ERR_LAUNCH;
     char name[64];
-    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,4,1,4,%d,%s>", NBW, DG ? "true" : "false");
+    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,%d,1,4,%d,%s>", TM, NBW, DG ? "true" : "false");
     cs_set_variant_(name);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
@@ -826,17 +912,23 @@ int launch_halo(const C2Plan& pl, hipStream_t st) {
         const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 256);
         dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
         cs_set_variant_(DG ? "conv2_halo_kernel<9,3,4,2,2,8,true>" : "conv2_halo_kernel<9,3,4,2,2,8,false>");
-        hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8, DG>), grid, dim3(256), 8 * 8192, st, p);
+        if (!allow_lds(conv2_halo_kernel<9, 3, 4, 2, 2, 8, DG>, 8 * 8192 + EPI_LDS)) return CS_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8, DG>), grid, dim3(256), 8 * 8192 + EPI_LDS, st, p);
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
     const int two = pl.ncc > 1;
-    switch (pl.nbw) {
-        case 3: return launch_cfg1<3, DG>(p, st, two);
-        case 4: return launch_cfg1<4, DG>(p, st, two);
-        case 5: return launch_cfg1<5, DG>(p, st, two);
-        default: return launch_cfg1<8, DG>(p, st, 0);
+#define CS_HALO_TM(TM_)                                         \
+    switch (pl.nbw) {                                           \
+        case 3: return launch_cfg1<TM_, 3, DG>(p, st, two);     \
+        case 4: return launch_cfg1<TM_, 4, DG>(p, st, two);     \
+        case 5: return launch_cfg1<TM_, 5, DG>(p, st, two);     \
+        default: return launch_cfg1<TM_, 8, DG>(p, st, 0);      \
     }
+    if (pl.tm == 2) { CS_HALO_TM(2) }
+    if (pl.tm == 3) { CS_HALO_TM(3) }
+    CS_HALO_TM(4)
+#undef CS_HALO_TM
 }
 
 #ifdef CS_DEBUG_V2
