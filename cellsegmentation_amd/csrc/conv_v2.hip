@@ -70,6 +70,8 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p; }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
+// the same where compiler-visible LDS reads of DMA-written bytes follow: they must not be hoisted above the wait
+template <int N> __device__ __forceinline__ void wait_vm_mem() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // one 16-row LDS block = two 1 KiB LDS-DMA pieces: lanes = 4 chunk columns x 16 rows; the second piece takes the other
@@ -692,6 +694,340 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
 }
 
 
+// =================================================================================================
+// Ring kernel: 1x1 convolutions of ANY contraction depth as a persistent, software-pipelined stream.  Stamped, a one-shot
+// workgroup of the kernel above spends most of its life with nothing in flight (first-load latency, then an epilogue behind
+// which no load is queued); two such workgroups per compute unit reach 3.4-4.3 TB/s on the layers that are HBM-bound, and the
+// first-generation kernel that served the deep contractions (C > 256) sat at ~2 TB/s / 15 % MFMA.  Here a workgroup keeps ONE
+// output-channel tile and walks (pixel tile, 64-channel chunk) steps over a ring of three 16 KiB LDS slots:
+//   step s:  weights of step s+2 -> registers | wait: own pieces of step s landed | barrier | DMA of step s+2 -> slot (s+2)%3
+//            | 4*TM MFMA of step s | on the last chunk of a pixel tile: epilogue, accumulators back to zero
+// so two steps of operands (per wave 8 KiB) are always in flight -- through every epilogue too.
+//   * EVERY load inside the loop is inline asm with hand-counted s_waitcnt: a load the compiler can see makes it insert a wait
+//     that counts only its own operations, which drains our younger DMA / weight loads as well (this is what made the first
+//     persistent attempt slower than the one-shot kernel).  The epilogue's residual / add operand therefore arrives by LDS-DMA
+//     (row arrangement, armed one pixel tile ahead during the previous epilogue), its mask words land in owned registers
+//     v[96:99]; stores are compiler-issued (they cause no waits) but their NUMBER per epilogue is fixed (operands that are
+//     absent use zero-sized buffers), because every later vmcnt immediate has to count them: E_OPS per epilogue.
+//   * step s needs the weights B(s) and the pieces DMA(s); issued after DMA(s): [E(s-2)] B(s+1) DMA(s+1) [E(s-1)] B(s+2)
+//     -> vmcnt(12 + E_OPS * (epilogues among steps s-1, s-2)).  Loads past the last step are issued with out-of-range
+//     offsets (they count, move nothing) so the immediates hold to the end.
+//   * the residual of the tile that finishes at step s was armed by E(s - NCC): for NCC >= 3 the wait above covers it, for
+//     NCC = 1, 2 the epilogue waits for vmcnt(E_OPS - 5 + 8 * NCC) (5 operations per 32-pixel tile: 2 stores, 1 bit store or
+//     mask load, 2 DMA).
+//   * the exchange between accumulator and row arrangement uses the residual's own 2 KiB of LDS per 32-pixel tile, rows of
+//     64 bytes, 16-byte slot = piece ^ ((row >> 2) & 3): conflict-free for both arrangements, and the DMA (which can only write
+//     lane-contiguous LDS) applies the swizzle on the global side.
+// LDS: 3 x 16 KiB + 4 waves x TM x 2 KiB = 80 KiB (TM = 4) -> two workgroups per compute unit.
+// =================================================================================================
+constexpr int R_MB = 96;
+
+template <int TM, bool DG> struct RingEpilogue {
+    static constexpr int E_OPS = 5 * TM + (DG ? 2 : 0);
+    const C2Params& p;
+    unsigned m0w = 0, m0w_next = 0xffffffffu, slab_row = 0;
+    int n_w;
+    bool alive;
+    unsigned region;           // LDS byte address of this wave's TM x 2 KiB
+    float sh[16];
+    float s1[8];
+    i32x4 q_res, q_bin;
+    __amdgpu_buffer_rsrc_t r_dst, r_bout, r_slab;
+
+    __device__ __forceinline__ RingEpilogue(const C2Params& p_, int n_w_, bool alive_, unsigned region_) : p(p_), n_w(n_w_), alive(alive_), region(region_) {}
+
+    // row arrangement of this kernel: lane L <-> LDS slot L of a 1 KiB half tile = row 16q + (L >> 2), slot L & 3, which holds
+    // piece (L & 3) ^ ((row >> 2) & 3) = (L & 3) ^ ((L >> 4) & 3) of that pixel's 64 bytes
+    __device__ __forceinline__ unsigned piece() const {
+        const unsigned lane = threadIdx.x & 63;
+        return (lane & 3u) ^ ((lane >> 4) & 3u);
+    }
+    __device__ __forceinline__ unsigned row_off_at(unsigned base, int i, int q) const {
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned m = base + 32u * i + 16u * q + (lane >> 2);
+        return (m < p.M && base != 0xffffffffu && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w + 8u * piece()) * 2u : OOB;
+    }
+    __device__ __forceinline__ unsigned bit_off_at(unsigned base, int i) const {      // slot 0 / 1 lanes: the dword of pixel q = 0 / 1
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned m = base + 32u * i + 16u * (lane & 1u) + (lane >> 2);
+        return (m < p.M && base != 0xffffffffu && alive && !(lane & 2u)) ? (m * (unsigned)p.NOUT + (unsigned)n_w) >> 3 : OOB;
+    }
+    __device__ __forceinline__ unsigned row_lds(int i, int q) const { return region + (unsigned)i * 2048u + (unsigned)q * 1024u + (threadIdx.x & 63u) * 16u; }
+    __device__ __forceinline__ unsigned acc_lds(int i, int j) const {
+        const unsigned lane = threadIdx.x & 63, l31 = lane & 31u;
+        return region + (unsigned)i * 2048u + l31 * 64u + (((2u * j + (lane >> 5)) ^ ((l31 >> 2) & 3u)) * 16u);
+    }
+
+    // residual / add rows (and mask words) of 32-pixel tile I of the pixel tile that starts at `base`: fly from now on
+    template <int I> __device__ __forceinline__ void arm(unsigned base) {
+        const unsigned v0 = row_off_at(base, I, 0), v1 = row_off_at(base, I, 1);
+        const unsigned lds = __builtin_amdgcn_readfirstlane(region + (unsigned)I * 2048u);
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+            "s_add_u32 m0, %0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %2, %3, 0 offen lds"
+            ::"s"(lds), "v"(v0), "v"(v1), "s"(q_res)
+            : "memory", "scc");
+        if constexpr (DG) {
+            const unsigned b = bit_off_at(base, I);
+            asm volatile("buffer_load_dword v[%c2], %0, %1, 0 offen" ::"v"(b), "s"(q_bin), "i"(R_MB + I) : "memory");
+        }
+    }
+    template <int... Is> __device__ __forceinline__ void arm_all(unsigned base, std::integer_sequence<int, Is...>) { (arm<Is>(base), ...); }
+
+    __device__ __forceinline__ void prefetch(unsigned first_base) {
+        const int lane = threadIdx.x & 63;
+        const int hh = lane >> 5;
+        const unsigned out_bytes = p.M * (unsigned)p.NOUT * 2u;
+        r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
+        r_bout = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? out_bytes >> 4 : 0u, 0x00020000);
+        r_slab = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, p.slab ? 0x7ffffff0u : 0u, 0x00020000);
+        q_res = make_rsrc(p.residual, p.residual ? out_bytes : 0u);
+        q_bin = make_rsrc(p.bits_in, p.bits_in ? out_bytes >> 4 : 0u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!DG && p.shift && alive) s = *reinterpret_cast<const float4*>(p.shift + n_w + 8 * g + 4 * hh);
+            sh[4 * g] = s.x; sh[4 * g + 1] = s.y; sh[4 * g + 2] = s.z; sh[4 * g + 3] = s.w;
+        }
+        // the only compiler-visible loads of the kernel: complete before the loop, so hipcc places no vmcnt wait inside it
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(sh[r]));
+        arm_all(first_base, std::make_integer_sequence<int, TM>{});
+    }
+
+    template <int I> __device__ __forceinline__ void operator()(const f32x16& acc) {
+        const int lane = threadIdx.x & 63;
+        const unsigned pc = piece();
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = DG ? acc[r] : acc[r] + sh[r];
+        if (p.residual) {
+            uint4 xa = lds_get(acc_lds(I, 0)), xb = lds_get(acc_lds(I, 1));
+            __builtin_amdgcn_wave_barrier();
+            swap32(xa.x, xa.z); swap32(xa.y, xa.w);
+            swap32(xb.x, xb.z); swap32(xb.y, xb.w);
+            const unsigned rw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float lo, hi;
+                unpack2(rw[k], lo, hi);
+                v[2 * k] += lo;
+                v[2 * k + 1] += hi;
+            }
+        }
+        if (!DG && p.act == CS_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        unsigned pk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        swap32(pk[0], pk[2]); swap32(pk[1], pk[3]);
+        swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
+        lds_put(acc_lds(I, 0), make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        lds_put(acc_lds(I, 1), make_uint4(pk[4], pk[5], pk[6], pk[7]));
+        __builtin_amdgcn_wave_barrier();
+        uint4 o0 = lds_get(row_lds(I, 0)), o1 = lds_get(row_lds(I, 1));
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (DG) {
+            if (p.bits_in) {
+                unsigned mbw;
+                asm volatile("v_mov_b32 %0, v[%c1]" : "=v"(mbw) : "i"(R_MB + I));
+                const unsigned w0 = quad<0x00>(mbw), w1 = quad<0x55>(mbw);
+                o0 = keep_bits8(o0, w0 >> (8u * pc));
+                o1 = keep_bits8(o1, w1 >> (8u * pc));
+            }
+            if constexpr (I == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s1[k] = 0.f;
+            }
+            if (p.slab) {
+                const unsigned ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float lo, hi;
+                    unpack2(ow[k], lo, hi);
+                    s1[2 * (k & 3)] += lo; s1[2 * (k & 3) + 1] += hi;
+                }
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), r_dst, row_off_at(m0w, I, 0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), r_dst, row_off_at(m0w, I, 1), 0, 0);
+        if constexpr (!DG) {
+            // always issued (a NULL bit plane has a zero-sized buffer): the vmcnt arithmetic of the loop counts it
+            unsigned w0 = 0u, w1 = 0u;
+            if (p.bits_out) {
+                w0 = pos_bits8(o0) << (8u * pc); w1 = pos_bits8(o1) << (8u * pc);
+                w0 |= quad<0xb1>(w0); w1 |= quad<0xb1>(w1);
+                w0 |= quad<0x4e>(w0); w1 |= quad<0x4e>(w1);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32((lane & 1) ? w1 : w0, r_bout, bit_off_at(m0w, I), 0, 0);
+        }
+        arm<I>(m0w_next);
+    }
+
+    __device__ __forceinline__ void finish() {
+        if constexpr (DG) {
+            const int lane = threadIdx.x & 63;
+            // lanes sharing a piece: any (lane >> 2) & 3, and slot = piece ^ g for g = lane >> 4
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = s1[k];
+                a += __shfl_xor(a, 4, 64);
+                a += __shfl_xor(a, 8, 64);
+                float t = a;
+#pragma unroll
+                for (int g = 1; g < 4; ++g) t += __shfl(a, ((lane & 3) ^ g) | (g << 4), 64);
+                s1[k] = t;
+            }
+            // lanes 0-3 hold piece = lane; always two stores (the loop's vmcnt arithmetic counts them)
+            const unsigned off = (lane < 4 && alive && p.slab) ? ((slab_row * 2u * (unsigned)p.NOUT + (unsigned)n_w + 8u * (unsigned)lane) * 4u) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(s1[0], s1[1], s1[2], s1[3])), r_slab, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(s1[4], s1[5], s1[6], s1[7])), r_slab, off, 16, 0);
+        }
+    }
+};
+
+template <int TM, int WM, int WN, bool DG>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void conv2_ring_kernel(C2Params p, int n_groups) {
+    static_assert(WM * WN == 4 && WM * TM == 4, "a ring slot holds 128 pixel rows");
+    constexpr int BM = 128, BN = WN * 32;
+    constexpr unsigned SLOT = 16384u, NSLOT = 3u;
+    using Epi = RingEpilogue<TM, DG>;
+    constexpr int E = Epi::E_OPS;
+    static_assert(12 + 2 * E <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+    // workgroup -> (output-channel tile, pixel-tile group): id = 8*slot + xcd; the channel tiles of one group sit on one XCD
+    const unsigned bid = blockIdx.x;
+    const unsigned gslot = bid >> 3;
+    const unsigned group = (gslot / (unsigned)p.n_ntiles) * 8u + (bid & 7u);
+    const int n0 = (int)(gslot % (unsigned)p.n_ntiles) * BN;
+    const int n_w = n0 + wn * 32;
+    const bool alive = n_w < p.NOUT;
+    if (group * BM >= p.M) return;
+    const int NCC = p.NCC;
+
+    unsigned qb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qb[i] = (unsigned)((wm * TM + (i < TM ? i : 0)) * 32 + l31);
+    const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
+    const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
+    const unsigned smem_base = lds_off(smem);
+    const unsigned hhb = (unsigned)hh * 256u;
+    const unsigned cf0 = 0xf0u;
+    const unsigned w_base = (unsigned)(n_w >> 5) * (unsigned)NCC * 4096u;
+
+    // this wave's two 16-row blocks (wave, wave + 4) of pixel tile mt: byte offset of (row, chunk column) or out of range
+    auto tile_voff = [&](unsigned mt, unsigned (&vo)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned m = mt * BM + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+            unsigned pix = m;
+            if (p.stride > 1) {
+                const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+                const unsigned x = m - yall * (unsigned)p.DW;
+                const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+                const unsigned y = yall - n * (unsigned)p.DH;
+                pix = (n * (unsigned)p.SH + y * (unsigned)p.stride) * (unsigned)p.SW + x * (unsigned)p.stride;
+            }
+            vo[j] = (m < p.M && mt != 0xffffffffu) ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+        }
+    };
+
+    Epi epi(p, n_w, alive, smem_base + NSLOT * SLOT + (unsigned)wave * (unsigned)(TM * 2048));
+    unsigned mt = group;                                    // the pixel tile being multiplied
+    epi.prefetch(mt * BM + (unsigned)(wm * TM * 32));
+    asm volatile("; v[96:255] are owned by the main loop" ::: "v96", "v255");
+    vzero_seq(std::make_integer_sequence<int, 16 * TM>{});
+
+    // fetch cursor = step s+2: pixel tile f_mt (~0: past the end), chunk f_c, ring slot f_slot
+    unsigned f_mt = mt, f_slot = 0;
+    int f_c = 0;
+    unsigned f_vo[2];
+    tile_voff(f_mt, f_vo);
+    auto advance_fetch = [&]() {
+        f_slot = f_slot == NSLOT - 1 ? 0u : f_slot + 1u;
+        if (++f_c == NCC) {
+            f_c = 0;
+            if (f_mt != 0xffffffffu) {
+                f_mt += (unsigned)n_groups;
+                if (f_mt * BM >= p.M) f_mt = 0xffffffffu;
+            }
+            tile_voff(f_mt, f_vo);
+        }
+    };
+    auto issue_b = [&]<int J>() {
+        const unsigned bv = (alive && f_mt != 0xffffffffu) ? (unsigned)lane * 16u : OOB;
+        bload4<J>(rsrc_b, bv, w_base + (unsigned)f_c * 4096u);
+    };
+    auto issue_a = [&]() {
+        const unsigned dst = smem_base + f_slot * SLOT;
+        dma_block(rsrc_a, dst + (unsigned)wave * 2048u, f_vo[0], (unsigned)f_c * 128u);
+        dma_block(rsrc_a, dst + (unsigned)(wave + 4) * 2048u, f_vo[1], (unsigned)f_c * 128u);
+    };
+    // prologue = steps -2 and -1 of the schedule
+    issue_b.template operator()<0>(); issue_a(); advance_fetch();
+    issue_b.template operator()<1>(); issue_a(); advance_fetch();
+
+    int c = 0;                        // chunk of the step being multiplied
+    unsigned slot = 0;
+    bool fin1 = false, fin2 = false;  // steps s-1 / s-2 ended with an epilogue
+    auto step = [&]<int CUR>() -> bool {
+        issue_b.template operator()<(CUR + 2) % 3>();
+        const int nfin = (int)fin1 + (int)fin2;
+        if (nfin == 0) wait_vm<12>();
+        else if (nfin == 1) wait_vm<12 + E>();
+        else wait_vm<12 + 2 * E>();
+        raw_barrier();
+        issue_a();
+        advance_fetch();
+        const unsigned sh_cur = slot * (unsigned)BM;       // the slot, in LDS rows
+        const bool fin = c == NCC - 1;
+        bool more = true;
+        if (!fin) {
+            tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, false>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0);
+            ++c;
+        } else {
+            const unsigned mt_next = mt + (unsigned)n_groups;
+            const bool has_next = mt_next * BM < p.M;
+            epi.m0w = mt * BM + (unsigned)(wm * TM * 32);
+            epi.m0w_next = has_next ? mt_next * BM + (unsigned)(wm * TM * 32) : 0xffffffffu;
+            epi.slab_row = mt * WM + wm;
+            auto on_tile = [&]<int i>(const f32x16& d) {
+                // the operands E(s - NCC) armed for this 32-pixel tile (NCC >= 3: older than what the step's own wait covered)
+                if (NCC == 1) wait_vm_mem<(E - 5 + 8 < 63 ? E - 5 + 8 : 63)>();
+                else if (NCC == 2) wait_vm_mem<(E - 5 + 16 < 63 ? E - 5 + 16 : 63)>();
+                epi.template operator()<i>(d);
+            };
+            tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, true>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0, on_tile);
+            epi.finish();
+            vzero_seq(std::make_integer_sequence<int, 16 * TM>{});
+            c = 0;
+            mt = mt_next;
+            more = has_next;
+        }
+        slot = slot == NSLOT - 1 ? 0u : slot + 1u;
+        fin2 = fin1;
+        fin1 = fin;
+        return more;
+    };
+    for (;;) {
+        if (!step.template operator()<0>()) break;
+        if (!step.template operator()<1>()) break;
+        if (!step.template operator()<2>()) break;
+    }
+    wait_vm<0>();                     // the out-of-range tail loads (LDS-DMA among them) are gone before the LDS is released
+}
+
 // ---- weights [ROWS][taps][COLS] bf16 (ROWS = destination channels, COLS = contraction channels, both staged layouts of
 // cs_weight_prep have this shape) -> MFMA-fragment order [row tile 32][chunk 64][tap][k16][lane][8]; flip = taps mirrored
 // (data gradient).  One thread per 16 bytes.
@@ -802,6 +1138,8 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     pl.rows = cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
     return true;
 }
+const bool g_ring_off = [] { const char* e = getenv("CELLSEG_NO_RING"); return e && atoi(e); }();     // A/B experiments only
+
 bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
     if (g->groups > 1) return false;
@@ -813,7 +1151,12 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (SC % 64 || NOUT % 64 || DH < 1 || DW < 1) return false;
     if (g->stride > 1 && (DH < 2 || DW < 2)) return false;
     const int ncc = SC / 64;
-    if (ncc > 4) return false;
+    if (g_ring_off && ncc > 4) return false;
+    // (isolated, tools/conv_microbench.py shows the first-generation kernel ahead on >= 16 chunks -- 24.5 vs 29.1 us on 1024 -> 256 at
+    // 19 x 19 -- but inside the training step the ring kernel wins on the family: 3.37 vs 3.43 ms per step; CELLSEG_RING_MAX_NCC
+    // declines deeper contractions for A/B runs)
+    static const int max_ncc = [] { const char* e = getenv("CELLSEG_RING_MAX_NCC"); return e ? atoi(e) : 1 << 20; }();
+    if (ncc > max_ncc) return false;
     const long long M = (long long)g->N * DH * DW;
     const unsigned long long src_bytes = (unsigned long long)g->N * SH * SW * SC * 2ull;
     if (M >= (1ll << 31) - 512 || src_bytes >= 0x80000000ull) return false;
@@ -821,6 +1164,7 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (NOUT % 128 == 0) cfg = 3;                       // 128 px x 128 ch, 1 x 4 waves of 4 tiles
     else if (NOUT == 64) cfg = ncc <= 2 ? 4 : 5;        // 2 x 2 waves: 256 px (4 tiles) / 128 px (2 tiles) x 64 ch
     if (!cfg) return false;
+    if (!g_ring_off) cfg = cfg == 3 ? 6 : 7;            // the ring kernel: 128 px x 128 ch (1 x 4 waves) / 128 px x 64 ch (2 x 2 waves)
     C2Params& p = pl.p;
     p = C2Params{};
     p.SH = SH; p.SW = SW; p.SC = SC; p.NS = g->N;
@@ -837,10 +1181,10 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     const unsigned long long wbytes = (unsigned long long)cs_ceil_div(NOUT, 32) * 32 * (unsigned long long)SC * 2ull;
     if (wbytes >= 0x80000000ull) return false;
     p.wpk_bytes = (unsigned)wbytes;
-    const int BM = cfg == 4 ? 256 : 128, BN = cfg == 3 ? 128 : 64;
+    const int BM = cfg == 4 ? 256 : 128, BN = (cfg == 3 || cfg == 6) ? 128 : 64;
     p.n_ntiles = cs_ceil_div(NOUT, BN);
     pl.cfg = cfg; pl.nbw = 0; pl.ncc = ncc;
-    pl.rows = cs_ceil_div(M, BM) * (cfg == 3 ? 1 : 2);
+    pl.rows = cs_ceil_div(M, BM) * ((cfg == 3 || cfg == 6) ? 1 : 2);
     return true;
 }
 
@@ -874,9 +1218,34 @@ int launch_gemm_t(const C2Params& p, hipStream_t st) {
     return CS_OK;
 }
 
+template <int TM, int WM, int WN, bool DG>
+int launch_ring_t(const C2Params& p, hipStream_t st) {
+    // persistent: each workgroup keeps one channel tile and walks every n_groups-th pixel tile.  The group count (a multiple of
+    // 8: one group per XCD slot) minimises rounds-of-residency x pixel tiles per workgroup; 512 workgroups are resident at once
+    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 128);
+    const unsigned cap = (n_mt + 7u) / 8u * 8u;
+    unsigned best = 8u;
+    unsigned long long best_cost = ~0ull;
+    for (unsigned g = 8u; g <= cap; g += 8u) {
+        const unsigned long long rounds = ((unsigned long long)g * (unsigned)p.n_ntiles + 511ull) / 512ull;
+        const unsigned long long cost = rounds * ((n_mt + g - 1u) / g) * 16ull + rounds;      // + a little for every extra round's ramp-up
+        if (cost <= best_cost) { best_cost = cost; best = g; }
+    }
+    const size_t lds = 3 * 16384 + 4 * (size_t)TM * 2048;
+    if (!allow_lds(conv2_ring_kernel<TM, WM, WN, DG>, lds)) return CS_ERR_LAUNCH;
+    char name[64];
+    snprintf(name, sizeof(name), "conv2_ring_kernel<%d,%d,%d,%s>", TM, WM, WN, DG ? "true" : "false");
+    cs_set_variant_(name);
+    hipLaunchKernelGGL((conv2_ring_kernel<TM, WM, WN, DG>), dim3(best * (unsigned)p.n_ntiles), dim3(256), lds, st, p, (int)best);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
 template <bool DG>
 int launch_gemm(const C2Plan& pl, hipStream_t st) {
     const C2Params& p = pl.p;
+    if (pl.cfg == 6) return launch_ring_t<4, 1, 4, DG>(p, st);
+    if (pl.cfg == 7) return launch_ring_t<2, 2, 2, DG>(p, st);
     if (pl.cfg == 3) {
         switch (pl.ncc) {
             case 1: return launch_gemm_t<1, 4, 1, 4, DG>(p, st);

@@ -26,14 +26,19 @@ SHAPES = [
     (2, 12, 12, 64, 128, 3, 1, 0),      # valid convolution: the data gradient's source is smaller than its destination
     (2, 9, 9, 64, 128, 3, 1, 2),        # pad 2: output larger than input
     (3, 21, 17, 192, 128, 3, 1, 1),     # three chunks
-    # 1x1: the whole pixel tile staged once (contraction <= 256 channels)
-    (2, 19, 19, 64, 256, 1, 1, 0),      # one chunk; data gradient: four chunks into 64 channels (2 x 2 waves of 2 tiles)
+    # 1x1: the persistent ring kernel (any contraction depth): (pixel tile, 64-channel chunk) steps over three LDS slots
+    (2, 19, 19, 64, 256, 1, 1, 0),      # one chunk (an epilogue every step); data gradient: four chunks into 64 channels (2 x 2 waves)
     (3, 21, 17, 256, 64, 1, 1, 0),      # four chunks into 64 channels; data gradient: one chunk, 1 x 4 waves
-    (2, 38, 38, 128, 512, 1, 1, 0),     # two chunks, four N tiles; data gradient not served (contraction 512)
+    (2, 38, 38, 128, 512, 1, 1, 0),     # two chunks, four N tiles; data gradient: eight chunks
     (2, 19, 19, 192, 128, 1, 1, 0),     # three chunks
-    (2, 75, 75, 64, 64, 1, 1, 0),       # 256 px x 64 ch tiles
-    (2, 38, 38, 128, 64, 1, 1, 0),      # two chunks, 256 px x 64 ch tiles
+    (2, 75, 75, 64, 64, 1, 1, 0),       # 64-channel tiles, many pixel tiles per workgroup
+    (2, 38, 38, 128, 64, 1, 1, 0),      # two chunks, 64-channel tiles
     (2, 37, 41, 256, 128, 1, 2, 0),     # the strided down-sampling 1x1 (forward only)
+    (3, 10, 10, 2048, 512, 1, 1, 0),    # 32 chunks (layer4 conv1); data gradient: 8 chunks into 2048 channels
+    (2, 19, 19, 1024, 256, 1, 1, 0),    # 16 chunks
+    (64, 19, 19, 64, 128, 1, 1, 0),     # 181 pixel tiles: several per workgroup, tail tile, re-armed operands
+    (40, 23, 23, 128, 64, 1, 1, 0),     # the same for the 2 x 2 wave layout, two chunks
+    (1, 5, 5, 320, 128, 1, 1, 0),       # a single, partial pixel tile; five chunks
 ]
 
 
@@ -99,7 +104,7 @@ def test_packed_fwd_and_dgrad(shape, dev):
         torch.cuda.synchronize()
         assert _relerr(_from_nhwc(y_plain), _from_nhwc(y_old)) < TOL
     else:
-        assert Cout % 64 != 0 or Cin % 64 != 0 or (Cout == 64 and Cin > 64 and R == 3), f"{shape}: forward unexpectedly not served"
+        assert Cout % 64 != 0 or Cin % 64 != 0 or (Cout == 64 and Cin > 64 and R == 3) , f"{shape}: forward unexpectedly not served"
 
     # ---------- data gradient
     if K.packed_supported(geom, BF, dgrad=True):
@@ -124,7 +129,6 @@ def test_packed_fwd_and_dgrad(shape, dev):
 def test_packed_declines_what_it_does_not_serve(dev):
     assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 2, 1), BF)          # stride 2
     assert not K.packed_supported(K.make_geom(2, 19, 19, 128, 64, 1, 1, 2, 0), BF, dgrad=True)      # strided 1x1 data gradient
-    assert not K.packed_supported(K.make_geom(2, 19, 19, 512, 128, 1, 1, 1, 0), BF)         # contraction > 256 channels (ring variant)
     assert not K.packed_supported(K.make_geom(2, 19, 19, 24, 128, 3, 3, 1, 1), BF)          # channels not a multiple of 64
     assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 1, 1), torch.float32)
     assert not K.packed_supported(K.make_geom(2, 1, 1, 64, 128, 3, 3, 1, 1), BF)            # 1x1 images (32x32 tiles at layer4)

@@ -28,10 +28,11 @@ GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vect
 # reference's fp32 gradients -- torch's own bf16 autocast (ATen / MIOpen kernels driven by the oracle's functional restatement, an
 # independent implementation) reaches cosine 0.918 / relative L2 0.40 on layer1.0.conv1.weight and 0.96-0.99 / 0.20-0.28 elsewhere
 # in the trunk, while the same oracle in fp32 on the GPU reproduces the golden gradients to <= 8e-4.  This library's bf16 path is
-# closer to fp32 than torch-bf16 on 11 of 13 tensors (0.921 / 0.39 on the worst).  The yardstick itself moves between fresh
-# boxes on that worst tensor (0.918 / 0.40 and 0.947 / 0.32 were both observed: MIOpen picks its algorithms per process), so
-# the test pins the library to the independent bf16 implementation's distance with that spread as slack (+25 % + 0.02 on the
-# relative error, 0.04 on the cosine), plus absolute floors.
+# closer to fp32 than torch-bf16 on 11 of 13 tensors (0.921 / 0.39 on the worst).  This library's figures repeat to the digit
+# between boxes; the yardstick's do not (MIOpen picks algorithms per process: layer1.0.conv1.weight 0.918 <-> 0.947,
+# layer2.0.conv2.weight 0.934 <-> 0.983 were all observed), so a per-tensor comparison against it is a coin toss.  The test
+# pins (a) every tensor to absolute floors and (b) the MEAN relative error / cosine over the probed tensors to the independent
+# bf16 implementation's means (+10 % + 0.01 / -0.01), which move by < 0.01 between runs.
 ABS_COS_FLOOR = 0.90
 ABS_REL_CEIL = 0.45
 
@@ -95,8 +96,12 @@ def test_bf16_training_gradients_against_reference_fp32(dev):
         print(f"{name:34s} this library bf16: cos {cos:.5f} rel {relerr:.4f}   torch bf16 autocast: cos {ycos:.5f} rel {yrel:.4f}")
         if cos < ABS_COS_FLOOR or relerr > ABS_REL_CEIL:
             errs.append(f"{name}: cos {cos:.4f} rel {relerr:.3f} outside the absolute band")
-        if relerr > 1.25 * yrel + 0.02 or cos < ycos - 0.04:
-            errs.append(f"{name}: cos {cos:.4f} rel {relerr:.3f} worse than the independent bf16 implementation ({ycos:.4f}, {yrel:.3f})")
+    names = sorted(ours)
+    m_rel, m_cos = sum(ours[n][1] for n in names) / len(names), sum(ours[n][0] for n in names) / len(names)
+    y_rel, y_cos = sum(yard[n][1] for n in names) / len(names), sum(yard[n][0] for n in names) / len(names)
+    print(f"mean over {len(names)} tensors: this library rel {m_rel:.4f} cos {m_cos:.5f}   torch bf16 autocast rel {y_rel:.4f} cos {y_cos:.5f}")
+    if m_rel > 1.10 * y_rel + 0.01 or m_cos < y_cos - 0.01:
+        errs.append(f"mean rel {m_rel:.4f} / cos {m_cos:.4f} worse than the independent bf16 implementation ({y_rel:.4f} / {y_cos:.4f})")
     assert not errs, "\n".join(errs)
 
 
