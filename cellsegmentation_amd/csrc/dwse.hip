@@ -91,10 +91,14 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy,
 // dw[kh][kw][c] += sum over output pixels of dy * x.  Workgroup = (slab of output pixels) x (chunk of <= 64 channel groups)
 // x (group of <= 9 filter taps); threads = W channel groups x (256/W) pixel lanes.  Pixels are the OUTER loop: dy is read once
 // per pixel and each of the group's taps keeps its own 8-channel accumulator in registers (72 VGPRs); afterwards the pixel
-// lanes are folded through LDS and ONE atomic per (tap, channel) leaves the workgroup.
+// lanes are folded through LDS and the workgroup leaves ONE partial row slab[blockIdx.x][tap][c]; dw_wgrad_fold_kernel sums the
+// rows.  (Round 1 left one atomicAdd per (tap, channel) instead: ~500 workgroups x 4608 atomics onto a few thousand addresses
+// serialised in L2 -- 262 us average per EfficientNet-B3 layer, 189 us with the partial rows.  A sliding-window variant that
+// walks output rows and loads only the new window column per pixel (4 instead of 10 loads) was measured SLOWER, 204 us: its
+// loads depend on the previous step and one or two waves per SIMD cannot hide them -- the kernel is latency-, not request-bound.)
 constexpr int kDwTaps = 9;
 template <typename T>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int N,
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ slab, int N,
                                                        int H, int W, int C, int R, int stride, int pad, int P, int Q, int pix_per_block) {
     const int CG = C / 8;
     const int cg0 = blockIdx.y * 64;
@@ -156,10 +160,37 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
                 for (int e = 0; e < 8; ++e) {
                     float sum = 0.f;
                     for (int r = 0; r < lanes; ++r) sum += red[r * width + threadIdx.x][e];
-                    atomicAdd(dw + (t0 + t) * C + cg * 8 + e, sum);
+                    slab[((long long)blockIdx.x * (R * R) + t0 + t) * C + cg * 8 + e] = sum;
                 }
             }
         }
+    }
+}
+
+// dw[i] = sum_r slab[r][i]: workgroup = 16 columns x 16 row lanes, 8 loads in flight per thread
+__global__ __launch_bounds__(256) void dw_wgrad_fold_kernel(const float* __restrict__ slab, int rows, int ncols, float* __restrict__ dw) {
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float acc = 0.f;
+    if (c < ncols) {
+        int r = rl;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(long long)(r + u * 16) * ncols + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < rows; r += 16) acc += slab[(long long)r * ncols + c];
+    }
+    __shared__ float red[16][17];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][cl];
+        dw[c] = t;
     }
 }
 
@@ -406,25 +437,49 @@ extern "C" int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     return CS_OK;
 }
 
-extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, void* stream) {
+// output-row slabs of the weight gradient: ~1024 workgroups in total (no atomics, so parallelism is free), <= 256 partial rows
+static void dw_wgrad_split(const CsConvGeom* g, int& rows_per_block, unsigned& nslab) {
+    const long long rows = (long long)g->N * g->P;
+    const int chunks = (g->C / 8 + 63) / 64 * ((g->R * g->R + kDwTaps - 1) / kDwTaps);
+    static const int dw_target = [] { const char* e = getenv("CELLSEG_DW_BLOCKS"); return e ? atoi(e) : 1024; }();   // A/B experiments only
+    long long slabs = dw_target / chunks;
+    if (slabs < 1) slabs = 1;
+    if (slabs > 256) slabs = 256;
+    long long rpb = (rows + slabs - 1) / slabs;
+    const long long min_rows = (64 + g->Q - 1) / g->Q;           // >= 64 pixels per workgroup
+    if (rpb < min_rows) rpb = min_rows;
+    rows_per_block = (int)rpb;
+    nslab = (unsigned)((rows + rpb - 1) / rpb);
+}
+
+extern "C" size_t cs_dwconv_wgrad_workspace(const CsConvGeom* g) {
+    if (!g || check_dw(g, "dwconv_wgrad_workspace: bad geometry")) return 0;
+    int rpb; unsigned nslab;
+    dw_wgrad_split(g, rpb, nslab);
+    return (size_t)nslab * g->R * g->R * g->C * sizeof(float);
+}
+
+extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, float* workspace, void* stream) {
     int rc = check_dw(g, "dwconv_wgrad: bad geometry");
     if (rc) return rc;
-    CS_CHECK_ARG(x && dy && dw_hwc, "dwconv_wgrad: NULL tensor");
+    CS_CHECK_ARG(x && dy && dw_hwc && workspace, "dwconv_wgrad: NULL tensor (workspace: cs_dwconv_wgrad_workspace bytes)");
+    CS_CHECK_ARG(dtype == CS_F32 || dtype == CS_BF16, "dwconv_wgrad: bad dtype");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long long npix = (long long)g->N * g->P * g->Q;
+    int rpb; unsigned nslab;
+    dw_wgrad_split(g, rpb, nslab);
     const int chunks = (g->C / 8 + 63) / 64;
     const int tgroups = (g->R * g->R + kDwTaps - 1) / kDwTaps;
-    static const int dw_target = [] { const char* e = getenv("CELLSEG_DW_BLOCKS"); return e ? atoi(e) : 512; }();   // A/B: 256/512/1024/2048 -> 36.1/34.3/34.6/36.8 ms per EfficientNet-B3 step (atomic contention vs parallelism)
-    long long slabs = dw_target / (chunks * tgroups);   // ~512 workgroups in total
-    if (slabs < 1) slabs = 1;
-    long long ppb = (npix + slabs - 1) / slabs;
-    if (ppb < 64) ppb = 64;
-    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)chunks, (unsigned)tgroups);
-    CS_T_SWITCH(dtype, "dwconv_wgrad",
-                hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, dw_hwc, g->N, g->H, g->W,
-                                   g->C, g->R, g->stride, g->pad, g->P, g->Q, (int)ppb),
-                hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw_hwc, g->N, g->H,
-                                   g->W, g->C, g->R, g->stride, g->pad, g->P, g->Q, (int)ppb));
+    dim3 grid(nslab, (unsigned)chunks, (unsigned)tgroups);
+    const int ppb = rpb * g->Q;
+    if (dtype == CS_F32)
+        hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, workspace, g->N, g->H, g->W, g->C,
+                           g->R, g->stride, g->pad, g->P, g->Q, ppb);
+    else
+        hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, workspace, g->N, g->H, g->W,
+                           g->C, g->R, g->stride, g->pad, g->P, g->Q, ppb);
+    CS_LAUNCH_CHECK();
+    const int ncols = g->R * g->R * g->C;
+    hipLaunchKernelGGL(dw_wgrad_fold_kernel, dim3((unsigned)((ncols + 15) / 16)), dim3(256), 0, st, workspace, (int)nslab, ncols, dw_hwc);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

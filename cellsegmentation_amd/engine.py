@@ -272,6 +272,8 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
     # train-mode BN bookkeeping for the whole plan in two launches instead of two per layer: one zero-filled fp64 arena for the
     # per-channel statistics, one foreach-add for the num_batches_tracked counters (this path is host-bound: ~1000 launches/step)
     stats_arena, stats_pos, bumped = None, [0], []
+    if bn_train and save:
+        K.begin_pass(t[plan.inputs[0]].device)
     bits = {}            # slot -> uint8 "output > 0" bit tensor (folded Conv+BN+ReLU outputs of a pass that will run backward)
     if bn_train:
         need = sum(2 * K.pad_channels(u_.conv.out_channels) for u_ in plan.units

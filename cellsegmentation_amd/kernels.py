@@ -510,7 +510,29 @@ def colsum_partial(g):
 
 
 # ---------------------------------------------------------------- BatchNorm (train mode)
+# Zero-initialised fp64 accumulators ([2, C] per BatchNorm reduction) come out of one pool per device that the engine clears ONCE
+# per training pass (begin_pass) instead of one fill launch per accumulator (EfficientNet-B3: 104 fills of 4.8 us per step).
+# Every user consumes its accumulator inside the call that took it (stream order), so clearing the whole pool at the start of the
+# next pass is safe; without begin_pass (direct calls from tests / tools) the pool is used once and then falls back to torch.zeros.
+_STATS_POOL_ELEMS = 1 << 19
+_stats_pools = {}
+
+
+def begin_pass(device):
+    pool = _stats_pools.get(device)
+    if pool is None:
+        _stats_pools[device] = [torch.zeros((_STATS_POOL_ELEMS,), dtype=torch.float64, device=device), 0]
+    else:
+        pool[0].zero_()
+        pool[1] = 0
+
+
 def new_stats(C, device):
+    pool = _stats_pools.get(device)
+    if pool is not None and pool[1] + 2 * C <= _STATS_POOL_ELEMS:
+        v = pool[0][pool[1]:pool[1] + 2 * C].view(2, C)
+        pool[1] += 2 * C
+        return v
     return torch.zeros((2, C), dtype=torch.float64, device=device)
 
 
@@ -626,8 +648,10 @@ def dwconv_dgrad(geom, dy, w_hwc):
 
 
 def dwconv_wgrad(geom, x, dy):
-    dw = torch.zeros((geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().cs_dwconv_wgrad(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw), _stream()), "dwconv_wgrad")
+    lib = _lib.load()
+    dw = torch.empty((geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
+    ws = torch.empty((max(lib.cs_dwconv_wgrad_workspace(ctypes.byref(geom)) // 4, 1),), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cs_dwconv_wgrad(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "dwconv_wgrad")
     return dw
 
 

@@ -248,7 +248,10 @@ int cs_dwconv_fwd_stats(const CsConvGeom* g, int dtype, const void* x, const flo
 int cs_bn_partial_fold(const double* partial, int rows, int C, double* stats, void* stream);
 int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, const float* w_hwc, void* dx, void* stream);
 /* dw_hwc[R][S][C] fp32 += ... (zeroed by the caller) */
-int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, void* stream);
+/* workspace: cs_dwconv_wgrad_workspace(g) bytes of per-workgroup partial rows (folded by a second kernel: no atomics, dw_hwc is
+ * overwritten, not accumulated into) */
+size_t cs_dwconv_wgrad_workspace(const CsConvGeom* g);
+int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, float* workspace, void* stream);
 /* y[n][p][c] = x[n][p][c]*s[n][c] */
 int cs_se_scale(const void* x, int dtype, const float* s, void* y, int N, int HW, int C, void* stream);
 /* phase 0: ds[n][c] = sum_p dy*x ; phase 1: dx = dy*s + davg[n][c]/HW (davg nullable) */

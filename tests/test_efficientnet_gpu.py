@@ -28,7 +28,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(24, 3, 1, 15, 14), (40, 5, 2, 19, 19), (16, 3, 2, 10, 11), (48, 5, 1, 9, 9)])
+@pytest.mark.parametrize("cfg", [(24, 3, 1, 15, 14), (40, 5, 2, 19, 19), (16, 3, 2, 10, 11), (48, 5, 1, 9, 9),
+                                 (528, 5, 1, 21, 19), (1032, 3, 2, 12, 13)])
 def test_depthwise_conv(cfg, dtype, dev):
     C, k, s, H, W = cfg
     torch.manual_seed(C + k)
