@@ -5,6 +5,8 @@
   c2s selection pass: eval fwd + softmax + adaptive top-k on 64-tile bags
   c4  EfficientNet-B3 tile classifier, bag 64, BN train                          (configs[3])
   c5  ResNet-50 encoder-decoder, batch 8 at 299x299, Dice, decoder training      (configs[4], per GPU)
+  c5x the same at 512x512, batch 4 (the reference's segmentation resolution, dataset/datasets.py MaskSet)
+  c1cpu the c1 step on the host cores through the oracle (torch CPU fp32): the reference's own CPU-runnable case timed beside c1
 One JSON line per config: images-or-tiles per second and ms/step (inputs resident in HBM)."""
 import json
 import os
@@ -46,7 +48,7 @@ def tiles(n, size=299, seed=1234):
     return base.repeat((n + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:n].contiguous().to(dev)
 
 
-which = sys.argv[1:] or ["c1", "c2f", "c2s", "c4", "c5"]
+which = sys.argv[1:] or ["c1", "c2f", "c2s", "c4", "c5", "c5x", "c1cpu"]
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
@@ -113,3 +115,41 @@ if "c5" in which:
         HF.dice_loss(HF.softmax_channel(m(x), 1), mask).backward()
         opt.step()
     run("c5 resnet50 segment B=8 299x299 bf16 (decoder training, Dice)", s5, 8, "images/s")
+if "c5x" in which:
+    m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
+    x = tiles(4, 512); mask = (torch.rand(4, 512, 512, device=dev) > 0.8).float()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4)
+
+    def s5x():
+        opt.zero_grad(set_to_none=True)
+        HF.dice_loss(HF.softmax_channel(m(x), 1), mask).backward()
+        opt.step()
+    run("c5x resnet50 segment B=4 512x512 bf16 (decoder training, Dice)", s5x, 4, "images/s")
+if "c1cpu" in which:
+    # test infrastructure only: the oracle is the CPU restatement of the reference (oracle/cellseg_oracle.py), timed as a baseline
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import _host_cpu
+    from oracle import cellseg_oracle as orc
+    model_name, cores = _host_cpu()
+    torch.set_num_threads(cores)
+    xc = synth.normalise(synth.ihc_tiles(8, 299, 1234))
+    cnt = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230]).float(); cl = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6])
+    sd = orc.empty_state_dict("resnet18")
+    synth.fill_state_dict(sd)
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith(("fc_tile", "upconv", "seg_out")):
+            v.requires_grad_()
+            params.append(v)
+    optc = torch.optim.Adam(params, lr=8e-5, weight_decay=1e-4)
+    orc.image_step_loss(sd, xc, cl, cnt, "resnet18")[2].backward()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        optc.zero_grad()
+        orc.image_step_loss(sd, xc, cl, cnt, "resnet18")[2].backward()
+        optc.step()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    print(json.dumps({"config": f"c1cpu resnet18 image counter B=8 fp32 on {cores} host cores ({model_name}), oracle port, median of 5",
+                      "value": round(8 / t, 2), "unit": "images/s", "ms_per_step": round(t * 1e3, 1)}), flush=True)

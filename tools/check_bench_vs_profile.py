@@ -4,7 +4,7 @@
     python tools/check_bench_vs_profile.py <bench.json (one JSON line)> <*_kernel_stats.csv> <steps in the profiled run, warm-up included>
 
 Fails (exit 1) when a `roofline.by_kernel` name is absent from the rocprofv3 table, when launch counts per step differ, when
-average durations disagree by more than 15 %, or when `roofline.kernel` is not the top conv-family row of the profile."""
+average durations disagree by more than max(15 %, 10 us), or when `roofline.kernel` is not the top conv-family row of the profile."""
 import csv
 import json
 import re
@@ -38,7 +38,9 @@ def main():
         if abs(calls / steps - row["launches_per_step"]) > 0.26:
             bad.append(f"{name}: {calls / steps:.2f} launches/step in the profile vs {row['launches_per_step']} in bench.py")
         avg_ms = tot / calls / 1e6
-        if abs(avg_ms - row["avg_ms"]) > 0.15 * max(avg_ms, row["avg_ms"]):
+        # a HIP-event bracket also sees the dispatch latency of the launch it brackets (2-9 us measured: 27.7 us in the kernel trace
+        # vs 32.8 us between events on conv2_halo_kernel<9,3,3,1,4,3,true>), which exceeds 15 % on the 30 us kernels
+        if abs(avg_ms - row["avg_ms"]) > max(0.15 * max(avg_ms, row["avg_ms"]), 0.010):
             bad.append(f"{name}: average {avg_ms * 1e3:.1f} us in the profile vs {row['avg_ms'] * 1e3:.1f} us by HIP events")
     conv = {k: v for k, v in prof.items() if k.startswith(("igemm", "wgrad_dma", "wgrad_kernel", "conv2_"))}
     top = max(conv, key=lambda k: conv[k][1]) if conv else None
