@@ -60,8 +60,7 @@ _SIGNATURES = {
     "cs_weight_prep_grouped": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "cs_conv2d_wgrad_batched_splits": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_conv2d_wgrad_batched": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, c_int, _P]),
-    "cs_wgrad_finalize_batched": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "cs_fold_partial_rows_batched": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "cs_wgrad_finalize_batched": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_conv2d_dgrad_partial_rows": (c_int, [POINTER(CsConvGeom)]),
     "cs_fold_partial_rows": (c_int, [_P, c_int, c_int, _P, _P]),
     "cs_wgrad_finalize_grouped": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

@@ -1180,49 +1180,6 @@ extern "C" int cs_fold_partial_rows(const float* partial, int rows, int n_out, f
     return CS_OK;
 }
 
-namespace {
-struct FoldTables { const float* partial[8]; float* out[8]; int rows[8]; };
-// slab_reduce_kernel over n <= 8 buffers: blockIdx.z = item (tables by value, static-index selection)
-__global__ __launch_bounds__(256) void fold_partial_batched_kernel(FoldTables t, int n_out) {
-    const float* src = nullptr; float* dst = nullptr; int rows = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if ((int)blockIdx.z == i) { src = t.partial[i]; dst = t.out[i]; rows = t.rows[i]; }
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    const int per = (rows + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per;
-    int r1 = r0 + per;
-    if (r1 > rows) r1 = rows;
-    float acc = 0.f;
-    if (c < n_out)
-        for (int r = r0 + rl; r < r1; r += 4) acc += src[(long long)r * 2 * n_out + c];
-    __shared__ float part[4][64];
-    part[rl][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (rl == 0 && c < n_out && r0 < rows)
-        atomicAdd(dst + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
-}
-}  // namespace
-
-extern "C" int cs_fold_partial_rows_batched(const float* const* partial_tab, const int* rows_tab, float* const* out_tab, int n_items,
-                                            int n_out, void* stream) {
-    CS_CHECK_ARG(partial_tab && rows_tab && out_tab && n_items >= 1 && n_items <= 8 && n_out > 0, "fold_partial_rows_batched: 1..8 items, HOST tables");
-    FoldTables t{};
-    int max_rows = 0;
-    for (int i = 0; i < n_items; ++i) {
-        CS_CHECK_ARG(partial_tab[i] && out_tab[i] && rows_tab[i] > 0, "fold_partial_rows_batched: NULL buffer or no rows");
-        t.partial[i] = partial_tab[i]; t.out[i] = out_tab[i]; t.rows[i] = rows_tab[i];
-        if (rows_tab[i] > max_rows) max_rows = rows_tab[i];
-    }
-    int chunks = max_rows / 64;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 32) chunks = 32;
-    hipLaunchKernelGGL(fold_partial_batched_kernel, dim3((n_out + 63) / 64, chunks, n_items), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
-                       n_out);
-    CS_LAUNCH_CHECK();
-    return CS_OK;
-}
 
 static int conv2d_dgrad_impl(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                              const void* mask, const unsigned char* mask_bits, void* dx, float* colsum, void* workspace, void* stream);

@@ -414,105 +414,124 @@ extern "C" int cs_weight_prep(const float* w, const float* scale, int dtype, int
     return CS_OK;
 }
 
-// Batched form for n layers of identical geometry: one launch, blockIdx.z = layer.  Tables (device memory) hold, per layer:
-// raw slabs, w, scale, rstd, mean, gsum, dw, dgamma, dbeta, dot (any of the optional ones may be NULL for every layer alike).
-struct FinalizeTables {      // by value in the kernel arguments, n <= 8 layers
+// Batched finalize for n <= 8 layers of identical geometry: ONE launch, one workgroup per (output channel k, layer).  The workgroup
+//   * folds the deferred column sums of its channel (gsum given as per-workgroup partial rows: grows[i] > 0), or reads the vector;
+//   * sums the split-K slabs of row k, writes dw[k][c][rs] (R*S > 1: the slab layout [rs][c] is turned through LDS so both the reads
+//     and the writes are contiguous) and accumulates dot[k] = sum w * raw in registers;
+//   * writes dgamma[k] = rstd * (dot - mean * gsum), dbeta[k] = gsum.
+// Round 1 did this in three launches per group (fold, finalize_a with one atomicAdd per workgroup into a zeroed dot[], finalize_b):
+// 63 launches and 0.64 ms per ResNet-50 step.  Tables travel BY VALUE (static indices only: a runtime index would spill them).
+struct FinalizeTables {
     const float* raw[8]; const float* w[8]; const float* scale[8]; const float* rstd[8]; const float* mean[8];
-    const float* gsum[8]; float* dw[8]; float* dgamma[8]; float* dbeta[8]; float* dot[8];
+    const float* gsum[8]; float* dw[8]; float* dgamma[8]; float* dbeta[8];
+    int grows[8];
     int has_scale, want_bn;
 };
 
-__global__ __launch_bounds__(256) void wgrad_finalize_a_batched_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit,
-                                                                       long long slab_stride, int want_dot) {
-    const int z = blockIdx.z, k = blockIdx.y;
-    // static indices only (a runtime index into the by-value tables would spill them to scratch)
-    const float* raw_s = nullptr; const float* w_s = nullptr; const float* sc_s = nullptr; float* dw_s = nullptr; float* dot_s = nullptr;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (z == i) { raw_s = t.raw[i]; w_s = t.w[i]; sc_s = t.scale[i]; dw_s = t.dw[i]; dot_s = t.dot[i]; }
-    const float* __restrict__ raw_p = raw_s;
-    const float* __restrict__ w = w_s;
-    const float sc = t.has_scale ? sc_s[k] : 1.f;
-    float* __restrict__ dw = dw_s;
-    const int per = Cin * RS;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float contrib = 0.f;
-    if (i < per) {
-        const int rs = i / Cin, c = i - rs * Cin;
-        const long long src = ((long long)k * RS + rs) * Cp + c;
-        float raw = 0.f;
-#pragma unroll 4
-        for (int s = 0; s < nsplit; ++s) raw += raw_p[s * slab_stride + src];
-        const long long o = (long long)k * per + c * RS + rs;
-        if (want_dot) contrib = w[o] * raw;
-        dw[o] = sc * raw;
-    }
-    if (want_dot) {
-        __shared__ float red[4];
-        contrib = wave_sum(contrib);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dot_s + k, red[0] + red[1] + red[2] + red[3]);
-    }
-}
-
-// R*S > 1: the slab layout is [k][rs][c] (c fastest), torch's is [k][c][rs] (rs fastest).  One thread per element either reads or
-// writes with a stride of R*S floats (every 64-byte line touched by R*S different waves); here a workgroup owns (k, 128 channels,
-// all taps), reads coalesced over c, turns the tile through LDS and writes 128*R*S CONTIGUOUS floats.
-constexpr int kFinCT = 128;
-__global__ __launch_bounds__(256) void wgrad_finalize_a_batched_tr_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit,
-                                                                          long long slab_stride, int want_dot) {
-    extern __shared__ float tile[];          // [RS][kFinCT + 1]
-    const int z = blockIdx.z, k = blockIdx.y, c0 = blockIdx.x * kFinCT;
-    const float* raw_s = nullptr; const float* w_s = nullptr; const float* sc_s = nullptr; float* dw_s = nullptr; float* dot_s = nullptr;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (z == i) { raw_s = t.raw[i]; w_s = t.w[i]; sc_s = t.scale[i]; dw_s = t.dw[i]; dot_s = t.dot[i]; }
-    const float* __restrict__ raw_p = raw_s;
-    const float* __restrict__ w = w_s;
-    float* __restrict__ dw = dw_s;
-    const float sc = t.has_scale ? sc_s[k] : 1.f;
-    const int cw = (Cin - c0) < kFinCT ? (Cin - c0) : kFinCT;       // channels of this tile
-    for (int idx = threadIdx.x; idx < RS * kFinCT; idx += 256) {
-        const int rs = idx / kFinCT, cl = idx - rs * kFinCT;
-        float raw = 0.f;
-        if (cl < cw) {
-            const long long src = ((long long)k * RS + rs) * Cp + c0 + cl;
-#pragma unroll 4
-            for (int s = 0; s < nsplit; ++s) raw += raw_p[s * slab_stride + src];
-        }
-        tile[rs * (kFinCT + 1) + cl] = raw;
-    }
+__device__ __forceinline__ float block_sum_256(float v, float* red /* [4] */) {
+    v = wave_sum(v);
     __syncthreads();
-    float contrib = 0.f;
-    const long long obase = ((long long)k * Cin + c0) * RS;
-    for (int idx = threadIdx.x; idx < cw * RS; idx += 256) {
-        const int cl = idx / RS, rs = idx - cl * RS;
-        const float raw = tile[rs * (kFinCT + 1) + cl];
-        if (want_dot) contrib += w[obase + idx] * raw;
-        dw[obase + idx] = sc * raw;
-    }
-    if (want_dot) {
-        __shared__ float red[4];
-        contrib = wave_sum(contrib);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dot_s + k, red[0] + red[1] + red[2] + red[3]);
-    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void wgrad_finalize_b_batched_kernel(FinalizeTables t, int K) {
-    const int z = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    const float* gsum = nullptr; const float* rstd = nullptr; const float* mean = nullptr; const float* dot = nullptr;
-    float* dgamma = nullptr; float* dbeta = nullptr;
+constexpr int kFinCT = 128;
+__global__ __launch_bounds__(256) void wgrad_finalize_fused_kernel(FinalizeTables t, int Cin, int RS, int Cp, int nsplit, long long slab_stride,
+                                                                   int gstride) {
+    extern __shared__ float tile[];          // R*S > 1: [RS][kFinCT + 1];  R*S == 1: [256]
+    __shared__ float red[4];
+    const int k = blockIdx.x, z = blockIdx.y;
+    const float* raw_s = nullptr; const float* w_s = nullptr; const float* sc_s = nullptr; const float* rstd_s = nullptr;
+    const float* mean_s = nullptr; const float* gsum_s = nullptr; float* dw_s = nullptr; float* dg_s = nullptr; float* db_s = nullptr;
+    int grows = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        if (z == i) { gsum = t.gsum[i]; rstd = t.rstd[i]; mean = t.mean[i]; dot = t.dot[i]; dgamma = t.dgamma[i]; dbeta = t.dbeta[i]; }
-    const float gs = gsum[k];
-    dgamma[k] = rstd[k] * (dot[k] - mean[k] * gs);
-    dbeta[k] = gs;
+        if (z == i) {
+            raw_s = t.raw[i]; w_s = t.w[i]; sc_s = t.scale[i]; rstd_s = t.rstd[i]; mean_s = t.mean[i]; gsum_s = t.gsum[i];
+            dw_s = t.dw[i]; dg_s = t.dgamma[i]; db_s = t.dbeta[i]; grows = t.grows[i];
+        }
+    const float* __restrict__ raw_p = raw_s;
+    const float* __restrict__ w = w_s;
+    float* __restrict__ dw = dw_s;
+    const float sc = t.has_scale ? sc_s[k] : 1.f;
+    const int want_bn = t.want_bn;
+
+    float gs = 0.f;
+    if (want_bn) {
+        if (grows > 0) {
+            float a = 0.f;
+            for (int r = threadIdx.x; r < grows; r += 256) a += gsum_s[(long long)r * gstride + k];
+            gs = block_sum_256(a, red);
+        } else {
+            gs = gsum_s[k];
+        }
+    }
+
+    float contrib = 0.f;
+    if (RS == 1) {
+        // CT channel lanes x SL split lanes (few channels, many slabs: 64 x 64 layers are split ~500 ways)
+        int CT = 256;
+        while (CT > 1 && (CT >> 1) >= Cin) CT >>= 1;
+        const int SL = 256 / CT;
+        const int cl = threadIdx.x % CT, sl = threadIdx.x / CT;
+        for (int c0 = 0; c0 < Cin; c0 += CT) {
+            const int c = c0 + cl;
+            float raw = 0.f;
+            if (c < Cin) {
+                const float* src = raw_p + (long long)k * Cp + c;
+                int s = sl;
+                for (; s + 3 * SL < nsplit; s += 4 * SL) {
+                    const float a0 = src[(long long)s * slab_stride], a1 = src[(long long)(s + SL) * slab_stride];
+                    const float a2 = src[(long long)(s + 2 * SL) * slab_stride], a3 = src[(long long)(s + 3 * SL) * slab_stride];
+                    raw += (a0 + a1) + (a2 + a3);
+                }
+                for (; s < nsplit; s += SL) raw += src[(long long)s * slab_stride];
+            }
+            if (SL > 1) {
+                __syncthreads();
+                tile[threadIdx.x] = raw;
+                __syncthreads();
+                if (sl == 0)
+                    for (int j = 1; j < SL; ++j) raw += tile[j * CT + cl];
+            }
+            if (sl == 0 && c < Cin) {
+                const long long o = (long long)k * Cin + c;
+                if (want_bn) contrib += w[o] * raw;
+                dw[o] = sc * raw;
+            }
+        }
+    } else {
+        for (int c0 = 0; c0 < Cin; c0 += kFinCT) {
+            const int cw = (Cin - c0) < kFinCT ? (Cin - c0) : kFinCT;       // channels of this tile
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < RS * kFinCT; idx += 256) {
+                const int rs = idx / kFinCT, cl = idx - rs * kFinCT;
+                float raw = 0.f;
+                if (cl < cw) {
+                    const float* src = raw_p + ((long long)k * RS + rs) * Cp + c0 + cl;
+#pragma unroll 4
+                    for (int s = 0; s < nsplit; ++s) raw += src[(long long)s * slab_stride];
+                }
+                tile[rs * (kFinCT + 1) + cl] = raw;
+            }
+            __syncthreads();
+            const long long obase = ((long long)k * Cin + c0) * RS;
+            for (int idx = threadIdx.x; idx < cw * RS; idx += 256) {
+                const int cl = idx / RS, rs = idx - cl * RS;
+                const float raw = tile[rs * (kFinCT + 1) + cl];
+                if (want_bn) contrib += w[obase + idx] * raw;
+                dw[obase + idx] = sc * raw;
+            }
+        }
+    }
+    if (want_bn) {
+        const float dot = block_sum_256(contrib, red);
+        if (threadIdx.x == 0) {
+            dg_s[k] = rstd_s[k] * (dot - mean_s[k] * gs);
+            db_s[k] = gs;
+        }
+    }
 }
 
 static int finalize_common(const float* raw, int nsplit, long long slab_stride, const float* w, const float* scale, const float* rstd,
@@ -653,31 +672,30 @@ extern "C" int cs_stage_conv_bn_multi(const CsStageDesc* desc, int n, int total_
     return CS_OK;
 }
 
-extern "C" int cs_wgrad_finalize_batched(const float* const* tables /* HOST: 10 consecutive tables of n pointers */, int n_items,
-                                         int nsplit, int Kp, int K, int Cin, int R, int S, int Cp, int want_bn, void* stream) {
+extern "C" int cs_wgrad_finalize_batched(const float* const* tables /* HOST: 9 consecutive tables of n pointers */, const int* gsum_rows,
+                                         int gsum_stride, int n_items, int nsplit, int Kp, int K, int Cin, int R, int S, int Cp, int want_bn,
+                                         void* stream) {
     CS_CHECK_ARG(tables && n_items >= 1 && n_items <= 8 && nsplit >= 1 && K > 0 && Cin > 0 && R > 0 && S > 0 && Cp >= Cin && Kp >= K,
                  "wgrad_finalize_batched: bad arguments (1..8 items, HOST pointer tables)");
+    CS_CHECK_ARG(R * S <= 64, "wgrad_finalize_batched: filters of more than 64 taps are not served");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     FinalizeTables t{};
     for (int i = 0; i < n_items; ++i) {
         t.raw[i] = tables[0 * n_items + i]; t.w[i] = tables[1 * n_items + i]; t.scale[i] = tables[2 * n_items + i];
         t.rstd[i] = tables[3 * n_items + i]; t.mean[i] = tables[4 * n_items + i]; t.gsum[i] = tables[5 * n_items + i];
         t.dw[i] = const_cast<float*>(tables[6 * n_items + i]); t.dgamma[i] = const_cast<float*>(tables[7 * n_items + i]);
-        t.dbeta[i] = const_cast<float*>(tables[8 * n_items + i]); t.dot[i] = const_cast<float*>(tables[9 * n_items + i]);
+        t.dbeta[i] = const_cast<float*>(tables[8 * n_items + i]);
+        t.grows[i] = gsum_rows ? gsum_rows[i] : 0;
+        CS_CHECK_ARG(t.raw[i] && t.dw[i], "wgrad_finalize_batched: NULL slab / dw");
+        CS_CHECK_ARG(!want_bn || (t.w[i] && t.rstd[i] && t.mean[i] && t.gsum[i] && t.dgamma[i] && t.dbeta[i]),
+                     "wgrad_finalize_batched: want_bn needs w, rstd, mean, gsum, dgamma, dbeta");
+        CS_CHECK_ARG(t.grows[i] == 0 || gsum_stride >= K, "wgrad_finalize_batched: partial rows need their row stride");
     }
     t.has_scale = tables[2 * n_items] != nullptr;
     t.want_bn = want_bn;
-    const int per = Cin * R * S;
-    if (R * S > 1 && R * S <= 64)
-        hipLaunchKernelGGL(wgrad_finalize_a_batched_tr_kernel, dim3((Cin + kFinCT - 1) / kFinCT, K, n_items), dim3(256),
-                           (size_t)R * S * (kFinCT + 1) * sizeof(float), st, t, Cin, R * S, Cp, nsplit, (long long)Kp * R * S * Cp, want_bn);
-    else
-        hipLaunchKernelGGL(wgrad_finalize_a_batched_kernel, dim3((per + 255) / 256, K, n_items), dim3(256), 0, st, t, Cin, R * S, Cp, nsplit,
-                           (long long)Kp * R * S * Cp, want_bn);
+    const size_t lds = R * S > 1 ? (size_t)R * S * (kFinCT + 1) * sizeof(float) : 256 * sizeof(float);
+    hipLaunchKernelGGL(wgrad_finalize_fused_kernel, dim3((unsigned)K, (unsigned)n_items), dim3(256), lds, st, t, Cin, R * S, Cp, nsplit,
+                       (long long)Kp * R * S * Cp, gsum_stride);
     CS_LAUNCH_CHECK();
-    if (want_bn) {
-        hipLaunchKernelGGL(wgrad_finalize_b_batched_kernel, dim3((K + 255) / 256, n_items), dim3(256), 0, st, t, K);
-        CS_LAUNCH_CHECK();
-    }
     return CS_OK;
 }

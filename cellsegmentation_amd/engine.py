@@ -556,17 +556,14 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         dws = [grad_buffer(c.weight) for c in convs]
         dgs = [grad_buffer(it.u.bn.weight) for it in items]
         dbs = [grad_buffer(it.u.bn.bias) for it in items]
-        dots = [take((convs[0].out_channels,)) for _ in items]
         # (single layers take the same path: its finalize folds deferred column sums, the stand-alone one does not)
         if n == 1 and items[0].a.xp is not None:
             slabs = K.stem_wgrad(geom, items[0].a.xp, items[0].dz, use_tr_read=use_tr_read).unsqueeze(0)     # [1, 1, K, 7, 7, 8]
         else:
             slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
-        pending = sum(1 for it in items if isinstance(it.gsum, K.PartialColsum) and it.gsum._vec is None)
-        gsums = K.fold_partial_batched([it.gsum for it in items], zeros=take((pending, geom.K)) if pending else None)
         K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
-                                 [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], gsums,
-                                 dws, dgs, dbs, dots, Cin)
+                                 [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
+                                 dws, dgs, dbs, Cin)
         for it, dw, dg, db in zip(items, dws, dgs, dbs):
             emit(it.ui, "weight", dw)
             if need(it.ui, "gamma"):

@@ -375,25 +375,6 @@ class PartialColsum:
         return self._sync()
 
 
-def fold_partial_batched(gsums, zeros=None):
-    """[PartialColsum | vector] (n <= 8) -> [vector]: every pending fold of the list in ONE launch.
-    zeros: optional zero-filled fp32 [n_pending, n_out] scratch (allocated here when omitted)."""
-    pend = [g for g in gsums if isinstance(g, PartialColsum) and g._vec is None]
-    if pend:
-        n_out = pend[0].n_out
-        if any(g.n_out != n_out for g in pend):
-            raise ValueError("fold_partial_batched: mixed widths")
-        if zeros is None:
-            zeros = torch.zeros((len(pend), n_out), dtype=torch.float32, device=pend[0].buf.device)
-        arrp = (ctypes.c_void_p * len(pend))(*[g.buf.data_ptr() for g in pend])
-        arrr = (ctypes.c_int * len(pend))(*[g.rows for g in pend])
-        arro = (ctypes.c_void_p * len(pend))(*[zeros[i].data_ptr() for i in range(len(pend))])
-        _lib.check(_lib.load().cs_fold_partial_rows_batched(arrp, arrr, arro, len(pend), n_out, _stream()), "fold_partial_rows_batched")
-        for i, g in enumerate(pend):
-            g._set(zeros[i])
-    return [g._sync() if isinstance(g, PartialColsum) else g for g in gsums]
-
-
 def colsum_vector(g):
     """A [C] fp32 tensor from either form of column sums."""
     return g.vector() if isinstance(g, PartialColsum) else g
@@ -458,8 +439,9 @@ def wgrad_batched(geom, xs, dys, use_tr_read=True):
     return slabs
 
 
-def wgrad_finalize_batched(slabs, ws, scales, rstds, means, gsums, dws, dgammas, dbetas, dots, Cin):
-    """Batched finalize for the eval-BN trunk: lists of n <= 8 tensors each."""
+def wgrad_finalize_batched(slabs, ws, scales, rstds, means, gsums, dws, dgammas, dbetas, Cin):
+    """Batched finalize for the eval-BN trunk: lists of n <= 8 tensors each, ONE launch.  gsums: [K] vectors or PartialColsum objects
+    (deferred column sums of a data-gradient launch: the kernel folds the partial rows of its channel itself)."""
     n, nsplit, Kp, R, S, Cp = slabs.shape
     K_ = dws[0].shape[0]
     want_bn = dgammas is not None
@@ -467,13 +449,22 @@ def wgrad_finalize_batched(slabs, ws, scales, rstds, means, gsums, dws, dgammas,
     def ptrs(lst):
         return [None] * n if lst is None else [t.data_ptr() for t in lst]
 
-    if gsums is not None and any(isinstance(g, PartialColsum) for g in gsums):
-        gsums = fold_partial_batched(gsums)
-    flat = [slabs[i].data_ptr() for i in range(n)] + ptrs(ws) + ptrs(scales) + ptrs(rstds) + ptrs(means) + ptrs(gsums) + ptrs(dws) + \
-        ptrs(dgammas) + ptrs(dbetas) + ptrs(dots)
+    grows, gstride, gptr = [0] * n, 0, [None] * n
+    if gsums is not None:
+        for i, g in enumerate(gsums):
+            if isinstance(g, PartialColsum) and g._vec is None:
+                grows[i], gptr[i] = g.rows, g.buf.data_ptr()
+                if gstride not in (0, 2 * g.n_out):
+                    raise ValueError("wgrad_finalize_batched: mixed partial-row strides")
+                gstride = 2 * g.n_out           # partial rows are [rows][2][n_out] in every producer
+            else:
+                gptr[i] = colsum_vector(g).data_ptr()
+    flat = [slabs[i].data_ptr() for i in range(n)] + ptrs(ws) + ptrs(scales) + ptrs(rstds) + ptrs(means) + gptr + ptrs(dws) + \
+        ptrs(dgammas) + ptrs(dbetas)
     table = (ctypes.c_void_p * len(flat))(*flat)
-    _lib.check(_lib.load().cs_wgrad_finalize_batched(table, n, nsplit, Kp, K_, Cin, R, S, Cp, 1 if want_bn else 0, _stream()),
-               "wgrad_finalize_batched")
+    rows_arr = (ctypes.c_int * n)(*grows)
+    _lib.check(_lib.load().cs_wgrad_finalize_batched(table, rows_arr, gstride, n, nsplit, Kp, K_, Cin, R, S, Cp, 1 if want_bn else 0,
+                                                     _stream()), "wgrad_finalize_batched")
 
 
 def wgrad_finalize(dw_raw, w, scale, rstd, mean, gsum, Cin, dw, dbias=None, dgamma=None, dbeta=None, accumulate=False, dot=None):

@@ -152,13 +152,10 @@ int cs_conv2d_dgrad_bits(const CsConvGeom* g, int dtype, const void* dy, const v
                          const uint8_t* mask_bits, void* dx, float* colsum, void* workspace, void* stream);
 /* Deferred column sums: with colsum == NULL and workspace != NULL (stride-1, ungrouped launches only) cs_conv2d_dgrad leaves the
  * per-workgroup partial rows in `workspace` -- row r holds the sums of destination-pixel tile r at [r * 2*C + c] -- and skips the
- * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows),
- * cs_fold_partial_rows_batched n <= 8 of them (HOST pointer / row-count arrays, passed by value) in one launch -- the engine folds
- * the buffers of a whole batched weight-gradient group together, right before its finalize. */
+ * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows);
+ * cs_wgrad_finalize_batched takes the partial rows as they are and folds each channel's column inside its own launch. */
 int cs_conv2d_dgrad_partial_rows(const CsConvGeom* g);
 int cs_fold_partial_rows(const float* partial, int rows, int n_out, float* out, void* stream);
-int cs_fold_partial_rows_batched(const float* const* partial_tab, const int* rows_tab, float* const* out_tab, int n_items, int n_out,
-                                 void* stream);
 /* weight gradient, raw split-K partials: dw_khwc[nsplit][K][R][S][Cp] fp32, slab z = sum over pixel slice z of
  *   dy (x) im2col(x), written with plain stores (no zero-fill needed; nsplit = cs_conv2d_wgrad_splits(g, grouped));
  *   cs_wgrad_finalize folds the slabs in a fixed order (bitwise reproducible). */
@@ -172,11 +169,13 @@ int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* d
 int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int n_items);
 int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
                             float* const* dw_tab, int n_items, int use_tr_read, void* stream);
-/* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped): `tables` = HOST array of 10*n_items (n <= 8) pointers:
- * [raw | w | scale | rstd | mean | gsum | dw | dgamma | dbeta | dot] x n_items (scale..gsum, dgamma, dbeta used only with
- * want_bn; dot zeroed by the caller). */
-int cs_wgrad_finalize_batched(const float* const* tables, int n_items, int nsplit, int Kp, int K, int Cin, int R, int S, int Cp,
-                              int want_bn, void* stream);
+/* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped) in ONE launch: `tables` = HOST array of 9*n_items
+ * (n <= 8) pointers: [raw | w | scale | rstd | mean | gsum | dw | dgamma | dbeta] x n_items (scale..gsum, dgamma, dbeta used only
+ * with want_bn).  gsum[i] is either the [K] vector (gsum_rows[i] == 0) or the per-workgroup partial rows a data-gradient
+ * launch left behind ([gsum_rows[i]][gsum_stride] fp32, cs_conv2d_partial_rows / cs_conv2d_packed_partial_rows): the kernel
+ * folds them itself.  gsum_rows: HOST array of n_items ints, or NULL (all vectors). */
+int cs_wgrad_finalize_batched(const float* const* tables, const int* gsum_rows, int gsum_stride, int n_items, int nsplit, int Kp, int K,
+                              int Cin, int R, int S, int Cp, int want_bn, void* stream);
 /* dw[K][Cin][R][S] (torch layout, ACCUMULATED into when accumulate!=0) = scale[k]*dw_khwc[k][r][s][c];
  * dbias[k] = scale[k]*gsum[k] (conv bias); and, when dgamma/dbeta non-NULL, the eval-mode BatchNorm parameter gradients
  *   dbeta[k] = gsum[k];  dgamma[k] = rstd[k]*( sum_j w[k][j]*dw_raw[k][j] - mean[k]*gsum[k] ). */
