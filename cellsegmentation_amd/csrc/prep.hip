@@ -174,24 +174,20 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
     T* w_chwk = reinterpret_cast<T*>(d.w_chwk);
     const long long t1 = w_khwc ? (long long)d.Kp * RS * d.Cp : 0;
     const long long t2 = w_chwk ? (long long)d.Cp * RS * d.Kp : 0;
-    // one thread = 8 consecutive staged elements (one 16-byte bf16 store): in every layout they are 8 consecutive CONTRACTION channels
-    // of one (destination channel, tap) -- c for the forward operand, k for the data-gradient one.  (Round 1 staged one element per
-    // thread: 2-byte stores and a full index decomposition + rsqrt per element, 152 us per ResNet-50 step.)
-    for (long long g8 = (long long)b * blockDim.x + threadIdx.x; g8 < (t1 + t2) / 8; g8 += (long long)nb * blockDim.x) {
-        const long long idx = g8 * 8;
+    for (long long idx = (long long)b * blockDim.x + threadIdx.x; idx < t1 + t2; idx += (long long)nb * blockDim.x) {
         int k, c, rs;
         const bool first = idx < t1;
         const long long j = first ? idx : idx - t1;
         if (first ? d.fwd_packed : d.bwd_packed) {
             // MFMA-fragment order of csrc/conv_v2.hip: [32-row tile][64-column chunk][tap][16-deep step][lane][8]; rows = destination
             // channels (k forward, c data gradient), columns = contraction channels; the data-gradient form mirrors the taps
-            const int lane = (int)((j >> 3) & 63), k16 = (int)((j >> 9) & 3);
+            const int e = (int)(j & 7), lane = (int)((j >> 3) & 63), k16 = (int)((j >> 9) & 3);
             long long u = j >> 11;
             const int t = (int)(u % RS); u /= RS;
             const int ncc = (first ? d.Cp : d.Kp) / 64;
             const int cc = (int)(u % ncc);
             const int rt = (int)(u / ncc);
-            const int row = rt * 32 + (lane & 31), col = cc * 64 + k16 * 16 + 8 * (lane >> 5);
+            const int row = rt * 32 + (lane & 31), col = cc * 64 + k16 * 16 + 8 * (lane >> 5) + e;
             if (first) { k = row; c = col; rs = t; }
             else { c = row; k = col; rs = RS - 1 - t; }
         } else if (first) {
@@ -199,21 +195,10 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
         } else {
             k = (int)(j % d.Kp); rs = (int)((j / d.Kp) % RS); c = (int)(j / ((long long)d.Kp * RS));
         }
-        float v[8];
-        if (first) {
-            const float sc = k < d.K ? (d.gamma ? d.gamma[k] : 1.f) * (1.0f / sqrtf(d.var[k] + d.eps)) : 0.f;
-            const float* src = d.w + ((long long)k * d.Cin + c) * RS + rs;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (k < d.K && c + e < d.Cin) ? src[(long long)e * RS] * sc : 0.f;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ke = k + e;
-                v[e] = (ke < d.K && c < d.Cin) ? d.w[((long long)ke * d.Cin + c) * RS + rs] * ((d.gamma ? d.gamma[ke] : 1.f) * (1.0f / sqrtf(d.var[ke] + d.eps)))
-                                               : 0.f;
-            }
-        }
-        store8<T>((first ? w_khwc : w_chwk) + j, v);
+        float v = 0.f;
+        if (k < d.K && c < d.Cin) v = d.w[((long long)k * d.Cin + c) * RS + rs] * ((d.gamma ? d.gamma[k] : 1.f) * (1.0f / sqrtf(d.var[k] + d.eps)));
+        if (first) w_khwc[j] = from_f32<T>(v);
+        else w_chwk[j] = from_f32<T>(v);
     }
 }
 
