@@ -14,8 +14,10 @@
 //  * Waves split the OUTPUT CHANNELS (1 x 4), every wave multiplies the whole pixel tile: 128 px x 32 ch per wave = 4 MFMA
 //    32x32x16 per 16-deep step fed by 4 ds_read_b128 + 1/4 buffer_load.
 //  * The accumulator is kept TRANSPOSED (channel on the register index, pixel on the lane): after bf16 packing and one
-//    v_permlane32_swap per dword pair every lane owns 16 contiguous bytes of its pixel's row -> residual / mask-bit loads and
-//    stores go straight between registers and HBM; no LDS pass, no barrier in the epilogue.
+//    v_permlane32_swap per dword pair every lane owns 16 contiguous bytes of its pixel's row.  The epilogue exchanges that
+//    arrangement for a row arrangement (4 consecutive lanes = 64 contiguous bytes of one pixel) through a wave-private LDS
+//    scratch -- no workgroup barrier -- because 64 lanes x 64 different rows is address-rate-bound (struct Epilogue).
+//  * 1x1 convolutions: a persistent ring kernel (conv2_ring_kernel) instead of one-shot workgroups.
 //  * All global->LDS and global->register traffic of the main loop is inline asm with hand-counted s_waitcnt vmcnt(N)
 //    (hipcc drains the queue at every use otherwise, see conv_igemm.hip).
 #include "cs_common.h"
@@ -597,106 +599,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
 
 
 // =================================================================================================
-// 1x1 convolutions with a short contraction (NCC <= 4 chunks of 64 channels): the whole BM x C pixel tile is staged ONCE,
-// one barrier per workgroup; a "tap" of the shared main loop is the next 64-channel chunk.  Forward with any stride (the
-// down-sampling 1x1 of model/resnet.py:183 gathers every stride-th pixel) and stride-1 data gradients.
-// =================================================================================================
-template <int NCC, int TM, int WM, int WN, bool DG>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void conv2_gemm_kernel(C2Params p) {
-    static_assert(WM * WN == 4 && NCC >= 1 && NCC <= 4 && TM >= 2 && TM <= 4, "layout");
-    constexpr int BM = WM * TM * 32, BN = WN * 32;
-    constexpr int NBW = BM / 64;                   // 16-row blocks per wave per chunk
-    constexpr unsigned CHB = BM * 128;             // bytes of one chunk of the tile
-    static_assert((NCC - 1) * CHB + 1536 < 65536, "ds_read offset field");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hh = lane >> 5;
-#ifdef CS_DEBUG_V2
-    unsigned long long t_stamp[6];
-    CS_STAMP(0);
-#endif
-    const unsigned bid = blockIdx.x;
-    const unsigned slot = bid >> 3;
-    const unsigned mtile = (slot / (unsigned)p.n_ntiles) * 8u + (bid & 7u);
-    const unsigned m0 = mtile * BM;
-    if (m0 >= p.M) return;
-    const int n0 = (int)(slot % (unsigned)p.n_ntiles) * BN;
-    const int n_w = n0 + wn * 32;
-    const bool alive = n_w < p.NOUT;
-    const unsigned m0w = m0 + (unsigned)(wm * TM * 32);
-
-    // rows of the LDS image = pixels of the tile in order; this lane's operand rows
-    unsigned qb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) qb[i] = (unsigned)((wm * TM + (i < TM ? i : 0)) * 32 + l31);
-    unsigned voff[NBW];
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const unsigned m = m0 + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
-        unsigned pix = m;
-        if (p.stride > 1) {
-            const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
-            const unsigned x = m - yall * (unsigned)p.DW;
-            const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
-            const unsigned y = yall - n * (unsigned)p.DH;
-            pix = (n * (unsigned)p.SH + y * (unsigned)p.stride) * (unsigned)p.SW + x * (unsigned)p.stride;
-        }
-        voff[j] = m < p.M ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
-    }
-    const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
-    const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
-    const unsigned bvoff = alive ? (unsigned)lane * 16u : OOB;
-    unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)(NCC * 4096);
-    const unsigned smem_base = lds_off(smem);
-
-    Epilogue<TM, true, DG> epi(p, m0w, n_w, mtile * WM + wm, alive, smem_base + (unsigned)NCC * CHB + (unsigned)wave * EPI_WAVE);
-    epi.prefetch();
-    CS_STAMP(4);
-    own_registers();
-    vzero_seq(std::make_integer_sequence<int, 16 * TM>{});
-    const unsigned hhb = (unsigned)hh * 256u;
-    const unsigned cf0 = 0xf0u;
-
-#pragma unroll
-    for (int cc = 0; cc < NCC; ++cc)
-#pragma unroll
-        for (int j = 0; j < NBW; ++j)
-            dma_block(rsrc_a, smem_base + (unsigned)cc * CHB + (unsigned)(wave + 4 * j) * 2048u, voff[j], (unsigned)cc * 128u);
-    bload4<0>(rsrc_b, bvoff, wsoff); wsoff += 4096u;
-    if constexpr (NCC > 1) { bload4<1>(rsrc_b, bvoff, wsoff); wsoff += 4096u; }
-    wait_vm<(NCC > 1 ? 8 : 4)>();
-    raw_barrier();
-    CS_STAMP(1);
-
-    auto tap = [&]<int T>() {
-        if constexpr (T + 2 < NCC) {
-            bload4<(T + 2) % 3>(rsrc_b, bvoff, wsoff);
-            wsoff += 4096u;
-        }
-        wait_vm<(T + 1 < NCC ? 4 : 0) + (T + 2 < NCC ? 4 : 0)>();
-        tap_mfma<TM, T % 3, 0, T * CHB, (T + 1) * CHB, T == 0, T != NCC - 1, true, T == NCC - 1>(qb[0], qb[1], qb[2], qb[3], 0u, 0u, hhb, cf0, epi);
-    };
-    [&]<int... Ts>(std::integer_sequence<int, Ts...>) { (tap.template operator()<Ts>(), ...); }(std::make_integer_sequence<int, NCC>{});
-    CS_STAMP(2);
-    epi.finish();
-#ifdef CS_DEBUG_V2
-    CS_STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)");
-    CS_STAMP(5);
-    if (p.dbg && lane == 0) {
-        unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
-        o[0] = t_stamp[0]; o[1] = t_stamp[4]; o[2] = t_stamp[1]; o[3] = t_stamp[2]; o[4] = t_stamp[3]; o[5] = t_stamp[5];
-    }
-#endif
-}
-
-
-// =================================================================================================
 // Ring kernel: 1x1 convolutions of ANY contraction depth as a persistent, software-pipelined stream.  Stamped, a one-shot
-// workgroup of the kernel above spends most of its life with nothing in flight (first-load latency, then an epilogue behind
+// workgroup (load the whole pixel tile, one barrier, multiply, epilogue -- round 2's first 1x1 kernel) spends most of its life with nothing in flight (first-load latency, then an epilogue behind
 // which no load is queued); two such workgroups per compute unit reach 3.4-4.3 TB/s on the layers that are HBM-bound, and the
 // first-generation kernel that served the deep contractions (C > 256) sat at ~2 TB/s / 15 % MFMA.  Here a workgroup keeps ONE
 // output-channel tile and walks (pixel tile, 64-channel chunk) steps over a ring of three 16 KiB LDS slots:
@@ -1138,8 +1042,6 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     pl.rows = cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
     return true;
 }
-const bool g_ring_off = [] { const char* e = getenv("CELLSEG_NO_RING"); return e && atoi(e); }();     // A/B experiments only
-
 bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
     if (g->groups > 1) return false;
@@ -1151,7 +1053,6 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (SC % 64 || NOUT % 64 || DH < 1 || DW < 1) return false;
     if (g->stride > 1 && (DH < 2 || DW < 2)) return false;
     const int ncc = SC / 64;
-    if (g_ring_off && ncc > 4) return false;
     // (isolated, tools/conv_microbench.py shows the first-generation kernel ahead on >= 16 chunks -- 24.5 vs 29.1 us on 1024 -> 256 at
     // 19 x 19 -- but inside the training step the ring kernel wins on the family: 3.37 vs 3.43 ms per step; CELLSEG_RING_MAX_NCC
     // declines deeper contractions for A/B runs)
@@ -1161,10 +1062,9 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     const unsigned long long src_bytes = (unsigned long long)g->N * SH * SW * SC * 2ull;
     if (M >= (1ll << 31) - 512 || src_bytes >= 0x80000000ull) return false;
     int cfg = 0;
-    if (NOUT % 128 == 0) cfg = 3;                       // 128 px x 128 ch, 1 x 4 waves of 4 tiles
-    else if (NOUT == 64) cfg = ncc <= 2 ? 4 : 5;        // 2 x 2 waves: 256 px (4 tiles) / 128 px (2 tiles) x 64 ch
+    if (NOUT % 128 == 0) cfg = 6;                       // ring kernel, 128 px x 128 ch: 1 x 4 waves of 4 tiles
+    else if (NOUT == 64) cfg = 7;                       // ring kernel, 128 px x 64 ch: 2 x 2 waves of 2 tiles
     if (!cfg) return false;
-    if (!g_ring_off) cfg = cfg == 3 ? 6 : 7;            // the ring kernel: 128 px x 128 ch (1 x 4 waves) / 128 px x 64 ch (2 x 2 waves)
     C2Params& p = pl.p;
     p = C2Params{};
     p.SH = SH; p.SW = SW; p.SC = SC; p.NS = g->N;
@@ -1181,10 +1081,10 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     const unsigned long long wbytes = (unsigned long long)cs_ceil_div(NOUT, 32) * 32 * (unsigned long long)SC * 2ull;
     if (wbytes >= 0x80000000ull) return false;
     p.wpk_bytes = (unsigned)wbytes;
-    const int BM = cfg == 4 ? 256 : 128, BN = (cfg == 3 || cfg == 6) ? 128 : 64;
+    const int BN = cfg == 6 ? 128 : 64;
     p.n_ntiles = cs_ceil_div(NOUT, BN);
     pl.cfg = cfg; pl.nbw = 0; pl.ncc = ncc;
-    pl.rows = cs_ceil_div(M, BM) * ((cfg == 3 || cfg == 6) ? 1 : 2);
+    pl.rows = cs_ceil_div(M, 128) * (cfg == 6 ? 1 : 2);
     return true;
 }
 
@@ -1201,21 +1101,6 @@ template <typename F> bool allow_lds(F fn, size_t bytes) {
     }
     if (n_done < 64) done[n_done++] = reinterpret_cast<const void*>(fn);
     return true;
-}
-
-template <int NCC, int TM, int WM, int WN, bool DG>
-int launch_gemm_t(const C2Params& p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32;
-    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, BM);
-    const size_t lds = (size_t)NCC * BM * 128 + EPI_LDS;
-    dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
-    char name[64];
-    snprintf(name, sizeof(name), "conv2_gemm_kernel<%d,%d,%d,%d,%s>", NCC, TM, WM, WN, DG ? "true" : "false");
-    cs_set_variant_(name);
-    if (!allow_lds(conv2_gemm_kernel<NCC, TM, WM, WN, DG>, lds)) return CS_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv2_gemm_kernel<NCC, TM, WM, WN, DG>), grid, dim3(256), lds, st, p);
-    CS_LAUNCH_CHECK();
-    return CS_OK;
 }
 
 template <int TM, int WM, int WN, bool DG>
@@ -1245,17 +1130,7 @@ template <bool DG>
 int launch_gemm(const C2Plan& pl, hipStream_t st) {
     const C2Params& p = pl.p;
     if (pl.cfg == 6) return launch_ring_t<4, 1, 4, DG>(p, st);
-    if (pl.cfg == 7) return launch_ring_t<2, 2, 2, DG>(p, st);
-    if (pl.cfg == 3) {
-        switch (pl.ncc) {
-            case 1: return launch_gemm_t<1, 4, 1, 4, DG>(p, st);
-            case 2: return launch_gemm_t<2, 4, 1, 4, DG>(p, st);
-            case 3: return launch_gemm_t<3, 4, 1, 4, DG>(p, st);
-            default: return launch_gemm_t<4, 4, 1, 4, DG>(p, st);
-        }
-    }
-    if (pl.cfg == 4) return pl.ncc == 1 ? launch_gemm_t<1, 4, 2, 2, DG>(p, st) : launch_gemm_t<2, 4, 2, 2, DG>(p, st);
-    return pl.ncc == 3 ? launch_gemm_t<3, 2, 2, 2, DG>(p, st) : launch_gemm_t<4, 2, 2, 2, DG>(p, st);
+    return launch_ring_t<2, 2, 2, DG>(p, st);
 }
 
 template <int TM, int NBW, bool DG>
