@@ -276,6 +276,44 @@ __device__ __forceinline__ unsigned pos_bits8(const uint4& o) {
     }
     return (t | (t >> 15)) & 0xffu;
 }
+// the same for values that went through ReLU (no negative element): > 0 <=> the bf16 pattern is >= 1, one packed-u16 minimum per dword
+// (asm: hipcc turns the builtin minimum into a compare + select per half)
+__device__ __forceinline__ unsigned nz_bits8(const uint4& o) {
+    const unsigned wds[4] = {o.x, o.y, o.z, o.w};
+    const unsigned ones = 0x00010001u;
+    unsigned u = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned t;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(wds[i]), "s"(ones));
+        u |= t << (2 * i);
+    }
+    return (u | (u >> 15)) & 0xffu;
+}
+// Row-arrangement offsets of one pixel tile, computed ONCE per tile: the byte offset of (32-pixel tile i, half q) is rb + (2i+q) * 16
+// rows, valid while its row index stays below M -- 3 instructions per access instead of a multiply-add chain per (i, q).
+struct TileOffs {
+    static constexpr unsigned NONE = 0x7fffff00u;      // M < 2^31 - 512: NONE + 16 * 7 neither wraps nor passes the test
+    unsigned rb, mr, bb, br;
+    // `piece`: which 16 bytes of the wave's 64 this lane handles; bits: lanes with (lane & 3) == q hold the dword of pixel q
+    __device__ __forceinline__ void set(unsigned base, bool ok, unsigned nout, unsigned n_w, unsigned piece) {
+        const unsigned lane = threadIdx.x & 63;
+        const bool live = ok && base != 0xffffffffu;
+        const unsigned m = base + (lane >> 2);
+        mr = live ? m : NONE;
+        rb = (m * nout + n_w + 8u * piece) * 2u;
+        const unsigned mbit = m + 16u * (lane & 1u);
+        br = (live && !(lane & 2u)) ? mbit : NONE;
+        bb = (mbit * nout + n_w) >> 3;
+    }
+    __device__ __forceinline__ unsigned row(unsigned M, unsigned nout, int i, int q) const {
+        const unsigned d = (unsigned)(2 * i + q);
+        return mr + 16u * d < M ? rb + d * (32u * nout) : OOB;
+    }
+    __device__ __forceinline__ unsigned bit(unsigned M, unsigned nout, int i) const {
+        return br + 32u * (unsigned)i < M ? bb + (unsigned)i * (4u * nout) : OOB;
+    }
+};
 // the 16 bytes with element k kept where bit k of b is set
 __device__ __forceinline__ uint4 keep_bits8(const uint4& o, unsigned b) {
     unsigned wds[4] = {o.x, o.y, o.z, o.w};
@@ -310,18 +348,7 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
     __device__ __forceinline__ Epilogue(const C2Params& p_, unsigned m0w_, int n_w_, unsigned slab_row_, bool alive_, unsigned scr_)
         : p(p_), m0w(m0w_), slab_row(slab_row_), n_w(n_w_), alive(alive_), scr(scr_) {}
 
-    // row arrangement: byte offset of (pixel 16q + (lane >> 2) of tile i, the lane's piece) in a [M][NOUT] bf16 tensor
-    __device__ __forceinline__ unsigned row_off_at(unsigned base, int i, int q) const {
-        const int lane = threadIdx.x & 63;
-        const unsigned m = base + 32u * i + 16u * q + (unsigned)(lane >> 2);
-        return (m < p.M && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w + 8u * (unsigned)(lane & 3)) * 2u : OOB;
-    }
-    // the dword of 32 channel bits of pixel 16q + (lane >> 2), q = the lane's piece (pieces 2 and 3: none)
-    __device__ __forceinline__ unsigned bit_off_at(unsigned base, int i) const {
-        const int lane = threadIdx.x & 63;
-        const unsigned m = base + 32u * i + 16u * (unsigned)(lane & 1) + (unsigned)(lane >> 2);
-        return (m < p.M && alive && !(lane & 2)) ? (m * (unsigned)p.NOUT + (unsigned)n_w) >> 3 : OOB;
-    }
+    TileOffs to;               // row arrangement: lane -> (pixel 16q + (lane >> 2) of tile i, piece lane & 3)
     __device__ __forceinline__ unsigned row_lds(int q) const {       // row arrangement: the lane's slot in the scratch
         const int lane = threadIdx.x & 63;
         return scr + (unsigned)(16 * q + (lane >> 2)) * EPI_ROW + (unsigned)(lane & 3) * 16u;
@@ -335,6 +362,7 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
         const int lane = threadIdx.x & 63;
         const int hh = lane >> 5;
         const unsigned out_bytes = p.M * (unsigned)p.NOUT * 2u;
+        to.set(m0w, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
         r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
         r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, p.residual ? out_bytes : 0u, 0x00020000);
         r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.bits_in), 0, p.bits_in ? out_bytes >> 4 : 0u, 0x00020000);
@@ -349,10 +377,10 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
         for (int i = 0; i < TM; ++i) {
             // a NULL operand has a zero-sized buffer: the loads return zeros without touching memory
             if constexpr (PRE_RES) {
-                rr[i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, i, 0), 0, 0));
-                rr[i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, i, 1), 0, 0));
+                rr[i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, i, 0), 0, 0));
+                rr[i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, i, 1), 0, 0));
             }
-            if constexpr (DG) mb[i] = __builtin_amdgcn_raw_buffer_load_b32(r_bin, bit_off_at(m0w, i), 0, 0);
+            if constexpr (DG) mb[i] = __builtin_amdgcn_raw_buffer_load_b32(r_bin, to.bit(p.M, (unsigned)p.NOUT, i), 0, 0);
         }
     }
 
@@ -367,8 +395,8 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
             uint4 x0, x1;
             if constexpr (PRE_RES) { x0 = rr[I][0]; x1 = rr[I][1]; }
             else {
-                x0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, I, 0), 0, 0));
-                x1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, row_off_at(m0w, I, 1), 0, 0));
+                x0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, I, 0), 0, 0));
+                x1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, I, 1), 0, 0));
             }
             lds_put(row_lds(0), x0);
             lds_put(row_lds(1), x1);
@@ -423,15 +451,16 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
                 }
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), r_dst, row_off_at(m0w, I, 0), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), r_dst, row_off_at(m0w, I, 1), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), r_dst, to.row(p.M, (unsigned)p.NOUT, I, 0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), r_dst, to.row(p.M, (unsigned)p.NOUT, I, 1), 0, 0);
         CS_ETICK(1);
         if (!DG && p.bits_out) {
             // byte j of a pixel's dword = channels 8j .. 8j+7 = piece j; OR over the quad, then lane (piece q) stores pixel q's dword
-            unsigned w0 = pos_bits8(o0) << (8u * piece), w1 = pos_bits8(o1) << (8u * piece);
+            const bool relu = p.act == CS_ACT_RELU;
+            unsigned w0 = (relu ? nz_bits8(o0) : pos_bits8(o0)) << (8u * piece), w1 = (relu ? nz_bits8(o1) : pos_bits8(o1)) << (8u * piece);
             w0 |= quad<0xb1>(w0); w1 |= quad<0xb1>(w1);       // [1,0,3,2]
             w0 |= quad<0x4e>(w0); w1 |= quad<0x4e>(w1);       // [2,3,0,1]
-            __builtin_amdgcn_raw_buffer_store_b32((lane & 1) ? w1 : w0, r_bout, bit_off_at(m0w, I), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((lane & 1) ? w1 : w0, r_bout, to.bit(p.M, (unsigned)p.NOUT, I), 0, 0);
         }
         CS_ETICK(2);
         CS_ETICK(3);
@@ -637,6 +666,9 @@ template <int TM, bool DG> struct RingEpilogue {
     float s1[8];
     i32x4 q_res, q_bin;
     __amdgpu_buffer_rsrc_t r_dst, r_bout, r_slab;
+#ifdef CS_DEBUG_V2
+    unsigned long long e_acc[4] = {0, 0, 0, 0}, e_t = 0;
+#endif
 
     __device__ __forceinline__ RingEpilogue(const C2Params& p_, int n_w_, bool alive_, unsigned region_) : p(p_), n_w(n_w_), alive(alive_), region(region_) {}
 
@@ -646,15 +678,11 @@ template <int TM, bool DG> struct RingEpilogue {
         const unsigned lane = threadIdx.x & 63;
         return (lane & 3u) ^ ((lane >> 4) & 3u);
     }
-    __device__ __forceinline__ unsigned row_off_at(unsigned base, int i, int q) const {
-        const unsigned lane = threadIdx.x & 63;
-        const unsigned m = base + 32u * i + 16u * q + (lane >> 2);
-        return (m < p.M && base != 0xffffffffu && alive) ? (m * (unsigned)p.NOUT + (unsigned)n_w + 8u * piece()) * 2u : OOB;
-    }
-    __device__ __forceinline__ unsigned bit_off_at(unsigned base, int i) const {      // slot 0 / 1 lanes: the dword of pixel q = 0 / 1
-        const unsigned lane = threadIdx.x & 63;
-        const unsigned m = base + 32u * i + 16u * (lane & 1u) + (lane >> 2);
-        return (m < p.M && base != 0xffffffffu && alive && !(lane & 2u)) ? (m * (unsigned)p.NOUT + (unsigned)n_w) >> 3 : OOB;
+    TileOffs cur, nxt;         // offsets of the pixel tile being finished / of the one whose operands are being armed
+    __device__ __forceinline__ void set_tile(unsigned base, unsigned base_next) {
+        m0w = base; m0w_next = base_next;
+        cur.set(base, alive, (unsigned)p.NOUT, (unsigned)n_w, piece());
+        nxt.set(base_next, alive, (unsigned)p.NOUT, (unsigned)n_w, piece());
     }
     __device__ __forceinline__ unsigned row_lds(int i, int q) const { return region + (unsigned)i * 2048u + (unsigned)q * 1024u + (threadIdx.x & 63u) * 16u; }
     __device__ __forceinline__ unsigned acc_lds(int i, int j) const {
@@ -663,8 +691,8 @@ template <int TM, bool DG> struct RingEpilogue {
     }
 
     // residual / add rows (and mask words) of 32-pixel tile I of the pixel tile that starts at `base`: fly from now on
-    template <int I> __device__ __forceinline__ void arm(unsigned base) {
-        const unsigned v0 = row_off_at(base, I, 0), v1 = row_off_at(base, I, 1);
+    template <int I> __device__ __forceinline__ void arm(const TileOffs& t) {
+        const unsigned v0 = t.row(p.M, (unsigned)p.NOUT, I, 0), v1 = t.row(p.M, (unsigned)p.NOUT, I, 1);
         const unsigned lds = __builtin_amdgcn_readfirstlane(region + (unsigned)I * 2048u);
         asm volatile(
             "s_mov_b32 m0, %0\n\t"
@@ -676,11 +704,11 @@ template <int TM, bool DG> struct RingEpilogue {
             ::"s"(lds), "v"(v0), "v"(v1), "s"(q_res)
             : "memory", "scc");
         if constexpr (DG) {
-            const unsigned b = bit_off_at(base, I);
+            const unsigned b = t.bit(p.M, (unsigned)p.NOUT, I);
             asm volatile("buffer_load_dword v[%c2], %0, %1, 0 offen" ::"v"(b), "s"(q_bin), "i"(R_MB + I) : "memory");
         }
     }
-    template <int... Is> __device__ __forceinline__ void arm_all(unsigned base, std::integer_sequence<int, Is...>) { (arm<Is>(base), ...); }
+    template <int... Is> __device__ __forceinline__ void arm_all(const TileOffs& t, std::integer_sequence<int, Is...>) { (arm<Is>(t), ...); }
 
     __device__ __forceinline__ void prefetch(unsigned first_base) {
         const int lane = threadIdx.x & 63;
@@ -700,12 +728,15 @@ template <int TM, bool DG> struct RingEpilogue {
         // the only compiler-visible loads of the kernel: complete before the loop, so hipcc places no vmcnt wait inside it
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(sh[r]));
-        arm_all(first_base, std::make_integer_sequence<int, TM>{});
+        TileOffs first;
+        first.set(first_base, alive, (unsigned)p.NOUT, (unsigned)n_w, piece());
+        arm_all(first, std::make_integer_sequence<int, TM>{});
     }
 
     template <int I> __device__ __forceinline__ void operator()(const f32x16& acc) {
         const int lane = threadIdx.x & 63;
         const unsigned pc = piece();
+        CS_ESTART();
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = DG ? acc[r] : acc[r] + sh[r];
@@ -732,11 +763,14 @@ template <int TM, bool DG> struct RingEpilogue {
         for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
         swap32(pk[0], pk[2]); swap32(pk[1], pk[3]);
         swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
+        CS_ETICK(0);
         lds_put(acc_lds(I, 0), make_uint4(pk[0], pk[1], pk[2], pk[3]));
         lds_put(acc_lds(I, 1), make_uint4(pk[4], pk[5], pk[6], pk[7]));
         __builtin_amdgcn_wave_barrier();
         uint4 o0 = lds_get(row_lds(I, 0)), o1 = lds_get(row_lds(I, 1));
         __builtin_amdgcn_wave_barrier();
+        asm volatile("" : "+v"(o0.x), "+v"(o1.w));
+        CS_ETICK(1);
         if constexpr (DG) {
             if (p.bits_in) {
                 unsigned mbw;
@@ -759,19 +793,22 @@ template <int TM, bool DG> struct RingEpilogue {
                 }
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), r_dst, row_off_at(m0w, I, 0), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), r_dst, row_off_at(m0w, I, 1), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), r_dst, cur.row(p.M, (unsigned)p.NOUT, I, 0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), r_dst, cur.row(p.M, (unsigned)p.NOUT, I, 1), 0, 0);
         if constexpr (!DG) {
             // always issued (a NULL bit plane has a zero-sized buffer): the vmcnt arithmetic of the loop counts it
             unsigned w0 = 0u, w1 = 0u;
             if (p.bits_out) {
-                w0 = pos_bits8(o0) << (8u * pc); w1 = pos_bits8(o1) << (8u * pc);
+                const bool relu = p.act == CS_ACT_RELU;
+                w0 = (relu ? nz_bits8(o0) : pos_bits8(o0)) << (8u * pc); w1 = (relu ? nz_bits8(o1) : pos_bits8(o1)) << (8u * pc);
                 w0 |= quad<0xb1>(w0); w1 |= quad<0xb1>(w1);
                 w0 |= quad<0x4e>(w0); w1 |= quad<0x4e>(w1);
             }
-            __builtin_amdgcn_raw_buffer_store_b32((lane & 1) ? w1 : w0, r_bout, bit_off_at(m0w, I), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((lane & 1) ? w1 : w0, r_bout, cur.bit(p.M, (unsigned)p.NOUT, I), 0, 0);
         }
-        arm<I>(m0w_next);
+        CS_ETICK(2);
+        arm<I>(nxt);
+        CS_ETICK(3);
     }
 
     __device__ __forceinline__ void finish() {
@@ -885,26 +922,37 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
     int c = 0;                        // chunk of the step being multiplied
     unsigned slot = 0;
     bool fin1 = false, fin2 = false;  // steps s-1 / s-2 ended with an epilogue
+#ifdef CS_DEBUG_V2
+    unsigned long long r_acc[5] = {0, 0, 0, 0, 0}, r_a, r_b;
+    unsigned r_tiles = 0, r_steps = 0;
+#define CS_RTICK(k) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_b)); r_acc[k] += r_b - r_a; r_a = r_b; } while (0)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_a));
+#else
+#define CS_RTICK(k)
+#endif
     auto step = [&]<int CUR>() -> bool {
         issue_b.template operator()<(CUR + 2) % 3>();
         const int nfin = (int)fin1 + (int)fin2;
         if (nfin == 0) wait_vm<12>();
         else if (nfin == 1) wait_vm<12 + E>();
         else wait_vm<12 + 2 * E>();
+        CS_RTICK(0);
         raw_barrier();
+        CS_RTICK(1);
         issue_a();
         advance_fetch();
+        CS_RTICK(2);
         const unsigned sh_cur = slot * (unsigned)BM;       // the slot, in LDS rows
         const bool fin = c == NCC - 1;
         bool more = true;
         if (!fin) {
             tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, false>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0);
             ++c;
+            CS_RTICK(3);
         } else {
             const unsigned mt_next = mt + (unsigned)n_groups;
             const bool has_next = mt_next * BM < p.M;
-            epi.m0w = mt * BM + (unsigned)(wm * TM * 32);
-            epi.m0w_next = has_next ? mt_next * BM + (unsigned)(wm * TM * 32) : 0xffffffffu;
+            epi.set_tile(mt * BM + (unsigned)(wm * TM * 32), has_next ? mt_next * BM + (unsigned)(wm * TM * 32) : 0xffffffffu);
             epi.slab_row = mt * WM + wm;
             auto on_tile = [&]<int i>(const f32x16& d) {
                 // the operands E(s - NCC) armed for this 32-pixel tile (NCC >= 3: older than what the step's own wait covered)
@@ -918,7 +966,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
             c = 0;
             mt = mt_next;
             more = has_next;
+            CS_RTICK(4);
+#ifdef CS_DEBUG_V2
+            ++r_tiles;
+#endif
         }
+#ifdef CS_DEBUG_V2
+        ++r_steps;
+#endif
         slot = slot == NSLOT - 1 ? 0u : slot + 1u;
         fin2 = fin1;
         fin1 = fin;
@@ -930,6 +985,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
         if (!step.template operator()<2>()) break;
     }
     wait_vm<0>();                     // the out-of-range tail loads (LDS-DMA among them) are gone before the LDS is released
+#ifdef CS_DEBUG_V2
+    if (p.dbg && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
+        o[0] = 2; o[1] = r_acc[0]; o[2] = r_acc[1]; o[3] = r_acc[2] + r_acc[3]; o[4] = r_acc[4]; o[5] = ((unsigned long long)r_steps << 32) | r_tiles;
+        if (p.act >= 200) { o[3] = r_acc[2]; o[1] = r_acc[3]; }
+        if (p.act >= 300) { o[1] = epi.e_acc[0]; o[2] = epi.e_acc[1]; o[3] = epi.e_acc[2]; o[4] = epi.e_acc[3]; }
+    }
+#endif
 }
 
 // ---- weights [ROWS][taps][COLS] bf16 (ROWS = destination channels, COLS = contraction channels, both staged layouts of

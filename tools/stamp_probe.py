@@ -18,10 +18,10 @@ for name in sys.argv[1:] or ["l1_3x3", "l2_3x3", "l3_3x3", "l4_3x3"]:
     wk, wc = K.weight_prep(w, None, torch.bfloat16, C, Kc, True, True)
     wp = K.pack_conv_weights(g, wk, False)
     shift = torch.zeros((Kc,), device=dev)
-    nblk = 8 * ((N * g.P * g.Q + 127) // 128 + 8) * max(1, Kc // 64)
+    nblk = 8 * ((N * g.P * g.Q + 127) // 128 + 8) * max(1, Kc // 64) + 4096
     buf = torch.zeros((nblk, 4, 6), dtype=torch.int64, device=dev)
     resid = torch.randn((N, g.P, g.Q, Kc), device=dev).to(torch.bfloat16) if os.environ.get("RESID") else None
-    ACT = 201 if os.environ.get("EPI") else K.CS_ACT_RELU
+    ACT = (301 if os.environ.get("EPI") == "2" else 201) if os.environ.get("EPI") else K.CS_ACT_RELU
     for _ in range(3):
         K.conv_fwd_packed(g, x, wp, shift, resid, K.CS_ACT_RELU, want_bits=True)
     torch.cuda.synchronize()
@@ -31,6 +31,23 @@ for name in sys.argv[1:] or ["l1_3x3", "l2_3x3", "l3_3x3", "l4_3x3"]:
     lib.cs_debug_set_stamp_buffer(None)
     b = buf.cpu().reshape(-1, 6)
     b = b[b[:, 0] != 0].double()
+    if float(b[:, 0].max()) == 2.0:           # ring kernel: per-phase sums over the workgroup's steps
+        packed = b[:, 5].long()
+        nt, ns = (packed & 0xffffffff).double(), (packed >> 32).double()
+        print(f"{name}: waves {len(b)}, tiles per workgroup med {nt.median():.0f} (min {nt.min():.0f}, max {nt.max():.0f}), steps med {ns.median():.0f}; per STEP (cycles):")
+        names_ = ["weights issue + wait for own pieces", "barrier", "DMA issue + non-final MFMA steps", "final step: MFMA + epilogue (per TILE)"]
+        if os.environ.get("EPI"):
+            names_ = ["non-final MFMA steps", "barrier", "DMA issue", "final step: MFMA + epilogue (per TILE)"]
+        dens = (ns, ns, ns, nt)
+        if os.environ.get("EPI") == "2":
+            names_ = ["epilogue per TILE: residual read + arithmetic", "exchange (LDS write, read back)", "mask / bits / stores", "arm next operands"]
+            dens = (nt, nt, nt, nt)
+        for n_, col, den in zip(names_, (1, 2, 3, 4), dens):
+            v = b[:, col] / den
+            print(f"    {n_:44s} med {v.median():8.0f}   p10 {v.quantile(0.1):8.0f}   p90 {v.quantile(0.9):8.0f}")
+        tot = (b[:, 1] + b[:, 2] + b[:, 3] + b[:, 4])
+        print(f"    total per workgroup med {tot.median():.0f} cycles")
+        continue
     if float(b[:, 0].max()) == 1.0:           # persistent kernel: per-phase sums over the workgroup's tiles
         nt = b[:, 5]
         print(f"{name}: waves {len(b)}, tiles per workgroup med {nt.median():.0f} (min {nt.min():.0f}, max {nt.max():.0f}); per tile (cycles):")
