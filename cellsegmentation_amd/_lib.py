@@ -58,7 +58,7 @@ _SIGNATURES = {
     "cs_wgrad_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "cs_conv2d_wgrad_splits": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_weight_prep_grouped": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "cs_conv2d_wgrad_batched_splits": (c_int, [POINTER(CsConvGeom), c_int]),
+    "cs_conv2d_wgrad_batched_splits": (c_int, [POINTER(CsConvGeom), c_int, c_int]),
     "cs_conv2d_wgrad_batched": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, c_int, _P]),
     "cs_wgrad_finalize_batched": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_conv2d_dgrad_partial_rows": (c_int, [POINTER(CsConvGeom)]),

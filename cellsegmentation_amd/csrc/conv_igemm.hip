@@ -1847,8 +1847,10 @@ extern "C" int cs_conv2d_wgrad_splits(const CsConvGeom* g, int grouped) {
     return wgrad_splits((long long)g->N * g->P * g->Q, g->K, g->R * g->S * cq, wide ? 128 : 64);
 }
 
-extern "C" int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int n_items) {
+extern "C" int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int dtype, int n_items) {
     if (!g || n_items < 1) return 0;
+    const int v2 = cs_wgrad2_splits_(g, dtype, n_items);         // bf16 stride-1 3x3 with C, K multiples of 64: wgrad_v2.hip
+    if (v2 > 0) return v2;
     return wgrad_splits((long long)g->N * g->P * g->Q, g->K, g->R * g->S * g->C, g->K > 64 ? 128 : 64, n_items);
 }
 
@@ -1857,6 +1859,7 @@ extern "C" int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const voi
     int rc = check_geom(g, dtype);
     if (rc != CS_OK) return rc;
     CS_CHECK_ARG(x_tab && dy_tab && dw_tab && n_items >= 1 && n_items <= 8, "conv2d_wgrad_batched: 1..8 items, HOST pointer arrays");
+    if (cs_wgrad2_splits_(g, dtype, n_items) > 0) return cs_wgrad2_launch_(g, dtype, x_tab, dy_tab, dw_tab, n_items, stream);
     WgradParams p{};
     const int ce = dtype == CS_F32 ? 4 : 8;
     for (int i = 0; i < n_items; ++i) { p.x_tab[i] = x_tab[i]; p.dy_tab[i] = dy_tab[i]; p.dw_tab[i] = dw_tab[i]; }

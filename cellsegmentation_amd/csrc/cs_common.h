@@ -109,6 +109,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- host side error plumbing (cs_api.cpp owns the storage) ----
 extern "C" void cs_set_error_(const char* msg);
 extern "C" void cs_set_variant_(const char* name);
+// wgrad_v2.hip: split-K slabs of the second-generation 3x3 weight gradient (0 = geometry not served) and its launch
+int cs_wgrad2_splits_(const CsConvGeom* g, int dtype, int n_items);
+int cs_wgrad2_launch_(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab, float* const* dw_tab, int n_items,
+                      void* stream);
 #define CS_CHECK_ARG(cond, msg)                         \
     do {                                                \
         if (!(cond)) {                                  \

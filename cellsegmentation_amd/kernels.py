@@ -428,7 +428,7 @@ def wgrad_batched(geom, xs, dys, use_tr_read=True):
     """Batched wgrad over len(xs) <= 8 layers of identical geometry.  Returns the split-K slab buffer [n, nsplit, K, R, S, Cp]."""
     n = len(xs)
     lib = _lib.load()
-    nsplit = lib.cs_conv2d_wgrad_batched_splits(ctypes.byref(geom), n)
+    nsplit = lib.cs_conv2d_wgrad_batched_splits(ctypes.byref(geom), _code(xs[0].dtype), n)
     slabs = torch.empty((n, nsplit, geom.K, geom.R, geom.S, geom.C), dtype=torch.float32, device=xs[0].device)
     for t in list(xs) + list(dys):
         _p(t)                                  # device / contiguity checks

@@ -163,10 +163,10 @@ int cs_conv2d_wgrad_splits(const CsConvGeom* g, int grouped);
 int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_khwc,
                     int use_tr_read, void* stream);
 /* Batched weight gradient for n_items layers of IDENTICAL geometry (the repeated blocks of a ResNet stage): one launch,
- * blockIdx.z = item*nsplit + slice, nsplit = cs_conv2d_wgrad_batched_splits(g, n_items) (fewer slices per layer ->
+ * blockIdx.z = item*nsplit + slice, nsplit = cs_conv2d_wgrad_batched_splits(g, dtype, n_items) (fewer slices per layer ->
  * proportionally less partial-slab traffic).  x_tab / dy_tab / dw_tab: HOST arrays of n_items (<= 8) device pointers (they
  * are passed to the kernel by value, no device table, no copy); dw_tab[i] is a [nsplit][K][R][S][Cp] fp32 buffer. */
-int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int n_items);
+int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int dtype, int n_items);
 int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
                             float* const* dw_tab, int n_items, int use_tr_read, void* stream);
 /* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped) in ONE launch: `tables` = HOST array of 9*n_items

@@ -328,7 +328,9 @@ def _cna(sd, pfx, x, stride, groups, train, act=True):
     return F.silu(y) if act else y
 
 
-def eff_encoder(sd, x, arch, train):
+def eff_encoder(sd, x, arch, train, sd_noise=None):
+    """sd_noise: optional iterator over the residual blocks in order -- per block the StochasticDepth("row") factor of torchvision 0.11.2
+    (ops/stochastic_depth.py: bernoulli(1 - p) / (1 - p), one value per sample) or None for the identity (eval / p = 0)."""
     x = _cna(sd, "features.0", x, 2, 1, train)
     table = eff_table(arch)
     for si, (e, k, s, cin, cout, n) in enumerate(table, start=1):
@@ -345,13 +347,17 @@ def eff_encoder(sd, x, arch, train):
             sc = torch.sigmoid(F.conv2d(sc, sd[f"{p}.{li}.fc2.weight"], sd[f"{p}.{li}.fc2.bias"]))
             h = sc * h; li += 1
             h = _cna(sd, f"{p}.{li}", h, 1, 1, train, act=False)
-            x = h + x if (st == 1 and ci == cout) else h          # stochastic depth: identity (eval / p = 0)
+            if st == 1 and ci == cout:
+                noise = next(sd_noise) if sd_noise is not None else None
+                x = (h if noise is None else h * noise.view(-1, 1, 1, 1)) + x
+            else:
+                x = h
     return _cna(sd, f"features.{len(table) + 1}", x, 1, 1, train)
 
 
-def eff_forward(sd, x, arch, mode, training=True):
+def eff_forward(sd, x, arch, mode, training=True, sd_noise=None):
     """MILEfficientNet.forward (efficientnet.py:305-333); freeze_bn is a no-op there. Dropout = identity."""
-    feat = _pooled(eff_encoder(sd, x, arch, training))
+    feat = _pooled(eff_encoder(sd, x, arch, training, sd_noise))
     if mode == "tile":
         return F.linear(feat, sd["fc_tile.1.weight"], sd["fc_tile.1.bias"])
     if mode == "image":

@@ -87,9 +87,9 @@ def test_se_and_rowscale(dev):
     assert _rel(out.cpu(), (a * rs.view(-1, 1, 1, 1) + b).cpu()) < 1e-6
 
 
-def _pair(arch, dev, dtype=torch.float32):
+def _pair(arch, dev, dtype=torch.float32, sd_prob=0.0):
     m = {"efficientnet_b0": EN.MILefficientnetB0, "efficientnet_b2": EN.MILefficientnetB2, "efficientnet_b3": EN.MILefficientnetB3}[arch](
-        stochastic_depth_prob=0.0, num_classes=2)
+        stochastic_depth_prob=sd_prob, num_classes=2)
     sd = m.state_dict()
     synth.fill_state_dict(sd)
     m.load_state_dict(sd)
@@ -158,3 +158,48 @@ def test_efficientnet_bf16_and_api(dev):
         m(x.to(dev))
     # segment mode freezes every group setmode() knows; `classifier` is never toggled (neither does the reference)
     assert sorted(k for k, p in m.named_parameters() if p.requires_grad) == ["classifier.1.bias", "classifier.1.weight"]
+
+
+def test_stochastic_depth_row_mode_vs_oracle(dev):
+    """EfficientNet-B0 with the reference's stochastic_depth_prob = 0.2 (model/efficientnet.py:101-114 on torchvision's
+    StochasticDepth(p, "row")): the training forward draws one bernoulli(1 - p) / (1 - p) factor per sample and residual block from
+    torch's CUDA generator; re-drawing the same sequence after re-seeding feeds the oracle, so loss and gradients must agree --
+    and they must DIFFER from the p = 0 network (some block was actually dropped)."""
+    n, arch = 8, "efficientnet_b0"
+    x = synth.normalise(synth.ihc_tiles(n, 64, 52))
+    labels = torch.tensor([i % 2 for i in range(n)])
+    m, osd = _pair(arch, dev, sd_prob=0.2)
+    m.setmode("tile")
+    m.train()
+    m.set_encoder_grads(True)
+    torch.manual_seed(1234)
+    loss = HF.cross_entropy(m(x.to(dev), freeze_bn=True), labels.to(dev))
+    loss.backward()
+    # the same draws, in plan order: one per residual block with p > 0
+    torch.manual_seed(1234)
+    noise, dropped = [], 0
+    for mod in m.modules():
+        if isinstance(mod, EN.MBConv) and mod.use_res_connect:
+            p = mod.stochastic_depth.p
+            if p > 0:
+                v = torch.empty((n,), dtype=torch.float32, device=dev).bernoulli_(1.0 - p).div_(1.0 - p)
+                dropped += int((v == 0).sum())
+                noise.append(v.cpu())
+            else:
+                noise.append(None)
+    assert dropped > 0, "the seed must drop at least one (sample, block) pair for the test to mean anything"
+    ref = F.cross_entropy(orc.eff_forward(osd, x, arch, "tile", training=True, sd_noise=iter(noise)), labels)
+    ref.backward()
+    plain = F.cross_entropy(orc.eff_forward({k: v.detach() for k, v in osd.items()}, x, arch, "tile", training=True), labels)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert abs(ref.item() - plain.item()) > 1e-3 * abs(ref.item())
+    gmax = max(float(v.grad.abs().max()) for v in osd.values() if v.grad is not None)
+    worst = []
+    for k, p_ in m.named_parameters():
+        if p_.grad is None or osd[k].grad is None:
+            continue
+        g, r = p_.grad.cpu(), osd[k].grad
+        worst.append((float((g - r).abs().max() / max(float(r.abs().max()), 1e-3 * gmax)), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 5e-3, worst[:5]

@@ -50,6 +50,8 @@ def main():
         cases = [("fwd", lambda: K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_RELU)),
                  ("dgrad", lambda: K.conv_dgrad(g, dy, wc, None, x)),
                  ("wgrad", lambda: K.conv_wgrad(g, x, dy, raw))]
+        nb = int(os.environ.get("BATCH", "1"))
+        cases.append(("wgrad_b", lambda: K.wgrad_batched(g, [x] * nb, [dy] * nb)))
         if os.environ.get("ONLY"):
             cases = [c for c in cases if c[0] in os.environ["ONLY"].split(",")]
         if dt == torch.bfloat16 and K.packed_supported(g, dt, False):
