@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(41))) void w
     static_assert(BL % 16 == 0 && XR % 8 == 0 && XR >= BL, "stage shape");
     constexpr unsigned DYB = BL * 128u, XB = XR * 128u, STAGE = DYB + XB;
     constexpr int NJ = BL / 16;
-    constexpr int NP_DY = BL / 8, NP = (BL + XR) / 8;              // 1 KiB DMA pieces (8 rows) per stage
+    constexpr int NP_DY = BL / 8;                                  // 1 KiB DMA pieces (8 rows) of the dy region; the x region has XR / 8
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,35 +130,32 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(41))) void w
     unsigned s_end = s_beg + p.stages_per_split;
     if (s_end > p.n_stages) s_end = p.n_stages;
 
-    // ---- DMA of one stage: piece q = wave + 4i covers LDS rows 8q .. 8q+7 of the stage (dy rows first, then x rows)
+    // ---- DMA of one stage: position piece q = wave + 4i = positions d0 + 8q .. 8q+7.  Row 8q+j of the x region and row 8q+j of the
+    // dy region are the SAME position, so one decode (two multiply-high divisions) serves both pieces.
     const unsigned xc_bytes = (unsigned)p.C * 2u, gc_bytes = (unsigned)p.K * 2u;
     auto issue = [&](unsigned s, unsigned buf) {
         const unsigned d0 = s * (unsigned)BL;
 #pragma unroll
-        for (int i = 0; i < (NP + 3) / 4; ++i) {
+        for (int i = 0; i < (XR / 8 + 3) / 4; ++i) {
             const int q = wave + 4 * i;
-            if (q < NP) {
-                const bool is_dy = q < NP_DY;
-                const unsigned row = (unsigned)(is_dy ? q : q - NP_DY) * 8u + (unsigned)(lane >> 3);      // row inside its region
+            if (q < XR / 8) {
+                const unsigned row = (unsigned)q * 8u + (unsigned)(lane >> 3);
                 const unsigned pos = d0 + row;
                 const unsigned rq = udivm(pos, p.mg_wp, p.sh_wp);
                 const unsigned col = pos - rq * (unsigned)p.Wp;
                 const unsigned n = udivm(rq, p.mg_hp, p.sh_hp);
                 const unsigned ry = rq - n * (unsigned)p.Hp;
-                const unsigned chunk = (unsigned)(lane & 7) ^ (((row >> 1) & 1u) << 2);
-                unsigned voff;
-                if (is_dy) {
-                    const bool ok = col < (unsigned)p.W && ry < (unsigned)p.H && n < (unsigned)p.N;
-                    voff = ok ? ((n * (unsigned)p.H + ry) * (unsigned)p.W + col) * gc_bytes + (unsigned)kt * 128u + chunk * 16u : OOB;
-                } else {
-                    const bool ok = col >= 1u && ry >= 1u && n < (unsigned)p.N;
-                    voff = ok ? ((n * (unsigned)p.H + (ry - 1u)) * (unsigned)p.W + (col - 1u)) * xc_bytes + (unsigned)ct * 128u + chunk * 16u : OOB;
+                const unsigned chunk = ((unsigned)(lane & 7) ^ (((row >> 1) & 1u) << 2)) * 16u;
+                const bool in_n = n < (unsigned)p.N;
+                const unsigned pix = (n * (unsigned)p.H + ry) * (unsigned)p.W + col;               // as a dy pixel; the x pixel is one row and one column back
+                const unsigned vx = (in_n && col >= 1u && ry >= 1u) ? (pix - (unsigned)p.W - 1u) * xc_bytes + (unsigned)ct * 128u + chunk : OOB;
+                const unsigned dstx = __builtin_amdgcn_readfirstlane(smem_base + buf * STAGE + DYB + (unsigned)q * 1024u);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dstx), "v"(vx), "s"(rsrc_x) : "memory");
+                if (q < NP_DY) {
+                    const unsigned vg = (in_n && col < (unsigned)p.W && ry < (unsigned)p.H) ? pix * gc_bytes + (unsigned)kt * 128u + chunk : OOB;
+                    const unsigned dstg = __builtin_amdgcn_readfirstlane(smem_base + buf * STAGE + (unsigned)q * 1024u);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dstg), "v"(vg), "s"(rsrc_g) : "memory");
                 }
-                const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * STAGE + (unsigned)q * 1024u);
-                if (is_dy)
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc_g) : "memory");
-                else
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc_x) : "memory");
             }
         }
     };
