@@ -53,7 +53,7 @@ _SIGNATURES = {
     "cs_pack_conv_weights": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P]),
     "cs_conv2d_packed_partial_rows": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_conv2d_fwd_packed": (c_int, [POINTER(CsConvGeom), _P, _P, _P, _P, c_int, _P, _P, _P]),
-    "cs_conv2d_dgrad_packed": (c_int, [POINTER(CsConvGeom), _P, _P, _P, _P, _P, _P, _P]),
+    "cs_conv2d_dgrad_packed": (c_int, [POINTER(CsConvGeom), _P, _P, _P, c_int, _P, _P, _P, _P]),
     "cs_conv2d_wgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, _P]),
     "cs_wgrad_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "cs_conv2d_wgrad_splits": (c_int, [POINTER(CsConvGeom), c_int]),

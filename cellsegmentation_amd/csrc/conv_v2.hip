@@ -45,6 +45,8 @@ struct C2Params {
     int DH, DW, NOUT;
     int Wp, Hp, PW, PH;            // padded-linear geometry of the source: Wp = SW + PW, Hp = SH + PH
     int stride;                    // 1x1 kernel only
+    int add_stride, AH, AW;        // ring data gradient: the add operand is a COMPACT [NS][AH][AW][NOUT] tensor that only exists at destination
+                                   // pixels (add_stride * y, add_stride * x) -- the gradient a strided 1x1 shortcut sends to the block input
     unsigned mg_dw, sh_dw, mg_dh, sh_dh, mg_wp, sh_wp, mg_hp, sh_hp;
     int NCC;                       // 64-channel chunks of the contraction
     int n_ntiles;
@@ -691,8 +693,20 @@ template <int TM, bool DG> struct RingEpilogue {
     }
 
     // residual / add rows (and mask words) of 32-pixel tile I of the pixel tile that starts at `base`: fly from now on
+    // byte offset of the add operand's row for (32-pixel tile i, half q): the destination row itself, or -- compact strided operand --
+    // the row of pixel (y / 2, x / 2) when both coordinates are even, nothing otherwise
+    __device__ __forceinline__ unsigned add_off(const TileOffs& t, int i, int q) const {
+        if (p.add_stride == 1) return t.row(p.M, (unsigned)p.NOUT, i, q);
+        const unsigned m = t.mr + 16u * (unsigned)(2 * i + q);
+        const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+        const unsigned x = m - yall * (unsigned)p.DW;
+        const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+        const unsigned y = yall - n * (unsigned)p.DH;
+        const unsigned mc = (n * (unsigned)p.AH + (y >> 1)) * (unsigned)p.AW + (x >> 1);
+        return (m < p.M && !((x | y) & 1u)) ? (mc * (unsigned)p.NOUT + (unsigned)n_w + 8u * piece()) * 2u : OOB;
+    }
     template <int I> __device__ __forceinline__ void arm(const TileOffs& t) {
-        const unsigned v0 = t.row(p.M, (unsigned)p.NOUT, I, 0), v1 = t.row(p.M, (unsigned)p.NOUT, I, 1);
+        const unsigned v0 = add_off(t, I, 0), v1 = add_off(t, I, 1);
         const unsigned lds = __builtin_amdgcn_readfirstlane(region + (unsigned)I * 2048u);
         asm volatile(
             "s_mov_b32 m0, %0\n\t"
@@ -717,7 +731,7 @@ template <int TM, bool DG> struct RingEpilogue {
         r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
         r_bout = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? out_bytes >> 4 : 0u, 0x00020000);
         r_slab = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, p.slab ? 0x7ffffff0u : 0u, 0x00020000);
-        q_res = make_rsrc(p.residual, p.residual ? out_bytes : 0u);
+        q_res = make_rsrc(p.residual, !p.residual ? 0u : p.add_stride == 1 ? out_bytes : (unsigned)(p.NS * p.AH * p.AW * p.NOUT) * 2u);
         q_bin = make_rsrc(p.bits_in, p.bits_in ? out_bytes >> 4 : 0u);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1109,12 +1123,16 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
     if (g->groups > 1) return false;
     if (g->R != 1 || g->S != 1 || g->pad != 0 || g->stride < 1) return false;
-    if (dgrad && g->stride != 1) return false;
+    // a STRIDED 1x1 data gradient is served in compact form: dx_compact[n][y][x] = W^T dy[n][y][x] on the P x Q grid (the values of
+    // the destination pixels (stride * y, stride * x); every other destination pixel is zero and never materialised -- the consumer
+    // adds the compact tensor through cs_conv2d_dgrad_packed's add_stride)
+    const bool compact = dgrad && g->stride != 1;
+    if (compact && g->stride != 2) return false;
     const int SC = dgrad ? g->K : g->C, NOUT = dgrad ? g->C : g->K;
     const int SH = dgrad ? g->P : g->H, SW = dgrad ? g->Q : g->W;
-    const int DH = dgrad ? g->H : g->P, DW = dgrad ? g->W : g->Q;
+    const int DH = dgrad ? (compact ? g->P : g->H) : g->P, DW = dgrad ? (compact ? g->Q : g->W) : g->Q;
     if (SC % 64 || NOUT % 64 || DH < 1 || DW < 1) return false;
-    if (g->stride > 1 && (DH < 2 || DW < 2)) return false;
+    if (!dgrad && g->stride > 1 && (DH < 2 || DW < 2)) return false;
     const int ncc = SC / 64;
     // (isolated, tools/conv_microbench.py shows the first-generation kernel ahead on >= 16 chunks -- 24.5 vs 29.1 us on 1024 -> 256 at
     // 19 x 19 -- but inside the training step the ring kernel wins on the family: 3.37 vs 3.43 ms per step; CELLSEG_RING_MAX_NCC
@@ -1132,8 +1150,9 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     p = C2Params{};
     p.SH = SH; p.SW = SW; p.SC = SC; p.NS = g->N;
     p.DH = DH; p.DW = DW; p.NOUT = NOUT;
-    p.stride = g->stride;
-    if (g->stride > 1) {
+    p.stride = dgrad ? 1 : g->stride;
+    p.add_stride = 1;
+    if (DW >= 2 && DH >= 2) {               // (destination pixel -> (n, y, x): the strided forward gather and the strided add operand)
         magic((unsigned)DW, p.mg_dw, p.sh_dw);
         magic((unsigned)DH, p.mg_dh, p.sh_dh);
     }
@@ -1306,13 +1325,23 @@ extern "C" int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const vo
     return launch_any(pl, reinterpret_cast<hipStream_t>(stream), false);
 }
 
-extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, const uint8_t* mask_bits,
-                                      void* dx, float* partial_rows, void* stream) {
+extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, int add_stride,
+                                      const uint8_t* mask_bits, void* dx, float* partial_rows, void* stream) {
     CS_CHECK_ARG(g && dy && w_packed && dx, "conv2d_dgrad_packed: NULL tensor");
+    CS_CHECK_ARG(add_stride == 1 || (add_stride == 2 && add), "conv2d_dgrad_packed: add_stride is 1, or 2 with a compact add operand");
     C2Plan pl;
     if (!plan_any(g, 1, pl)) {
         cs_set_error_("conv2d_dgrad_packed: geometry not served by the packed-operand kernel (ask cs_conv2d_packed_supported first)");
         return CS_ERR_UNSUPPORTED;
+    }
+    if (g->stride != 1)
+        CS_CHECK_ARG(!add && !mask_bits && !partial_rows,
+                     "conv2d_dgrad_packed: a strided 1x1 data gradient is written in compact [N][P][Q][C] form, without add / mask / column sums");
+    if (add_stride == 2) {
+        CS_CHECK_ARG(pl.cfg >= 6 && pl.p.DH >= 2 && pl.p.DW >= 2, "conv2d_dgrad_packed: a strided add operand is served by the 1x1 (ring) kernel only");
+        pl.p.add_stride = 2;
+        pl.p.AH = (pl.p.DH + 1) / 2;
+        pl.p.AW = (pl.p.DW + 1) / 2;
     }
     pl.p.src = dy; pl.p.wpk = w_packed; pl.p.dst = dx;
     pl.p.residual = add; pl.p.act = CS_ACT_NONE;

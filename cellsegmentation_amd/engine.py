@@ -183,7 +183,29 @@ def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits):
         return False, False
     pkf = K.packed_supported(geom, dtype, dgrad=False)
     pkb = bool(need_bwd) and K.packed_supported(geom, dtype, dgrad=True) and (u.src not in plan.relu_slots or u.src in bits)
+    if pkb and geom.stride != 1:
+        # a strided 1x1 data gradient is served in COMPACT form (kernels.CompactGrad): only where the other consumer of the block
+        # input is the stride-1 1x1 convolution whose packed data gradient runs AFTER this one in backward order and adds it
+        pkb = _compact_partner(plan, u, geom, dtype, bits) is not None
     return pkf, pkb
+
+
+def _compact_partner(plan, u, geom, dtype, bits):
+    """The unit whose data gradient will take u's compact gradient as its strided add operand, or None."""
+    others = [(i, v) for i, v in enumerate(plan.units) if v is not u and v.kind == "conv" and v.src == u.src]
+    if len(others) != 1 or plan.consumers.get(u.src, 0) != 2:
+        return None
+    iv, v = others[0]
+    iu = plan.units.index(u)
+    c = v.conv
+    if iv > iu or v.grouped or v.act not in (ACT_NONE, ACT_RELU) or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0):
+        return None
+    if u.src in plan.relu_slots and u.src not in bits:
+        return None
+    gv = K.make_geom(geom.N, geom.H, geom.W, geom.C, K.pad_channels(c.out_channels), 1, 1, 1, 0)
+    if not K.packed_supported(gv, dtype, dgrad=True):
+        return None
+    return v
 
 
 _STAGE_EPOCH = [0]
@@ -668,7 +690,11 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 mbits = state.bits.get(u.src) if mask is not None else None
                 if mbits is not None:
                     mask = None
-                if getattr(a.st, "bwd_packed", False):
+                if getattr(a.st, "bwd_packed", False) and geom.stride != 1:
+                    if final or pending is not None:
+                        raise RuntimeError(f"{u.name}: compact strided data gradient out of order (it must be the first contribution)")
+                    dx = K.conv_dgrad_packed(geom, dz, a.st.w_chwk)          # kernels.CompactGrad: consumed as a strided add operand
+                elif getattr(a.st, "bwd_packed", False):
                     if mask is not None:
                         raise RuntimeError(f"{u.name}: packed data-gradient operand staged but the ReLU mask is not a bit tensor")
                     if final:
@@ -678,10 +704,14 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                 elif final:
                     # column sums of the finished gradient feed its producer's BN/bias gradients: left as per-workgroup partial
                     # rows where the launch allows it (the batched finalize folds them; one small launch less per layer)
+                    if isinstance(pending, K.CompactGrad):
+                        raise RuntimeError(f"{u.name}: a compact gradient reached a data gradient that cannot add it")
                     cs = take((geom.C,)) if (geom.stride != 1 or u.grouped) else None
                     dx, gsum_cache[u.src] = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, colsum=cs, grouped=u.grouped,
                                                          defer_colsum=True, mask_bits=mbits)
                 else:
+                    if isinstance(pending, K.CompactGrad):
+                        raise RuntimeError(f"{u.name}: a compact gradient reached a data gradient that cannot add it")
                     dx = K.conv_dgrad(geom, dz, a.st.w_chwk, add=pending, mask=mask, grouped=u.grouped, mask_bits=mbits)
                 grads[u.src] = dx
         elif u.kind == "dw":

@@ -287,15 +287,37 @@ def conv_fwd_packed(geom, x, w_packed, shift=None, residual=None, act=CS_ACT_NON
     return (y, bits) if want_bits else y
 
 
+class CompactGrad:
+    """The data gradient of a stride-2 1x1 convolution in compact form: `t` [N][P][Q][C] holds the values of the destination pixels
+    (2y, 2x); every other pixel of that gradient is zero and was never written.  Only a packed 1x1 data gradient can consume it
+    (conv_dgrad_packed(add=CompactGrad))."""
+
+    def __init__(self, t, stride):
+        self.t, self.stride = t, stride
+
+
 def conv_dgrad_packed(geom, dy, w_packed, add=None, mask_bits=None, want_colsum=False):
-    """-> dx, or (dx, PartialColsum) with want_colsum."""
-    dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
+    """-> dx, or (dx, PartialColsum) with want_colsum.  A stride-2 1x1 geometry returns a CompactGrad (no add / mask / column sums);
+    `add` may be such a CompactGrad of the same destination."""
     lib = _lib.load()
+    if geom.stride != 1:
+        if add is not None or mask_bits is not None or want_colsum:
+            raise ValueError("conv_dgrad_packed: a strided 1x1 data gradient is compact -- no add, mask or column sums")
+        dxc = torch.empty((geom.N, geom.P, geom.Q, geom.C), dtype=dy.dtype, device=dy.device)
+        _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad_packed(
+            ctypes.byref(geom), _p(dy), _p(w_packed), None, 1, None, _p(dxc), None, _stream()), extra_tensors=-0.75), "conv2d_dgrad_packed")
+        return CompactGrad(dxc, geom.stride)
+    add_stride = 1
+    if isinstance(add, CompactGrad):
+        add_stride, add = add.stride, add.t
+        if tuple(add.shape) != (geom.N, (geom.H + 1) // 2, (geom.W + 1) // 2, geom.C):
+            raise ValueError("conv_dgrad_packed: compact add operand of another destination")
+    dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     rows = lib.cs_conv2d_packed_partial_rows(ctypes.byref(geom), 1) if want_colsum else 0
     ws = torch.empty((rows, 2 * geom.C), dtype=torch.float32, device=dy.device) if want_colsum else None
     _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad_packed(
-        ctypes.byref(geom), _p(dy), _p(w_packed), _p(add), _p(mask_bits), _p(dx), _p(ws), _stream()),
-        extra_tensors=int(add is not None) + (1.0 / 16 if mask_bits is not None else 0.0)), "conv2d_dgrad_packed")
+        ctypes.byref(geom), _p(dy), _p(w_packed), _p(add), add_stride, _p(mask_bits), _p(dx), _p(ws), _stream()),
+        extra_tensors=(int(add is not None) if add_stride == 1 else 0.25) + (1.0 / 16 if mask_bits is not None else 0.0)), "conv2d_dgrad_packed")
     if want_colsum:
         return dx, PartialColsum(ws, rows, geom.C)
     return dx

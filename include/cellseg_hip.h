@@ -319,15 +319,21 @@ int cs_segmented_topk(const float* probs, const int32_t* groups, const int32_t* 
  *   cs_conv2d_fwd_packed       : y = act(conv(x, w) + shift[k] + residual); positive_bits (nullable) as cs_conv2d_fwd_bits.
  *   cs_conv2d_dgrad_packed     : dx = (conv_transpose(dy, w) + add) masked by mask_bits (nullable, as cs_conv2d_dgrad_bits);
  *                                partial_rows (nullable): fp32 [cs_conv2d_packed_partial_rows(g, 1)][2][C] per-workgroup column
- *                                sums of the stored dx (first C entries of a row), folded by cs_fold_partial_rows*. */
+ *                                sums of the stored dx (first C entries of a row), folded by cs_fold_partial_rows*.
+ *                                A STRIDE-2 1x1 geometry (the shortcut of a down-sampling block, model/resnet.py:183) is served in
+ *                                COMPACT form: dx is [N][P][Q][C], the values of destination pixels (2y, 2x); every other pixel of
+ *                                that gradient is zero and is never written (add, mask_bits, partial_rows must be NULL).  Its
+ *                                consumer -- the 1x1 data gradient that accumulates the block input's gradient -- takes it as
+ *                                `add` with add_stride = 2: added at even (y, x) only, nothing elsewhere (add_stride = 1: an
+ *                                ordinary destination-shaped operand). */
 int cs_conv2d_packed_supported(const CsConvGeom* g, int dgrad);
 size_t cs_conv2d_packed_weight_bytes(const CsConvGeom* g, int dgrad);
 int cs_pack_conv_weights(const CsConvGeom* g, int dgrad, const void* w_staged, void* w_packed, void* stream);
 int cs_conv2d_packed_partial_rows(const CsConvGeom* g, int dgrad);
 int cs_conv2d_fwd_packed(const CsConvGeom* g, const void* x, const void* w_packed, const float* shift, const void* residual, int act,
                          void* y, uint8_t* positive_bits, void* stream);
-int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, const uint8_t* mask_bits,
-                           void* dx, float* partial_rows, void* stream);
+int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_packed, const void* add, int add_stride,
+                           const uint8_t* mask_bits, void* dx, float* partial_rows, void* stream);
 
 /* ---- stem on a pixel-paired image (Conv2d(3, 64, 7, stride 2, padding 3), model/resnet.py:111) ---------------------------
  * With 3 channels padded to one 16-byte chunk per pixel the implicit GEMM walks 49 chunks of which 147/392 elements are real.

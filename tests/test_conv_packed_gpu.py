@@ -33,7 +33,7 @@ SHAPES = [
     (2, 19, 19, 192, 128, 1, 1, 0),     # three chunks
     (2, 75, 75, 64, 64, 1, 1, 0),       # 64-channel tiles, many pixel tiles per workgroup
     (2, 38, 38, 128, 64, 1, 1, 0),      # two chunks, 64-channel tiles
-    (2, 37, 41, 256, 128, 1, 2, 0),     # the strided down-sampling 1x1 (forward only)
+    (2, 37, 41, 256, 128, 1, 2, 0),     # the strided down-sampling 1x1 (its data gradient is compact: test_compact_strided_gradient)
     (3, 10, 10, 2048, 512, 1, 1, 0),    # 32 chunks (layer4 conv1); data gradient: 8 chunks into 2048 channels
     (2, 19, 19, 1024, 256, 1, 1, 0),    # 16 chunks
     (64, 19, 19, 64, 128, 1, 1, 0),     # 181 pixel tiles: several per workgroup, tail tile, re-armed operands
@@ -107,7 +107,7 @@ def test_packed_fwd_and_dgrad(shape, dev):
         assert Cout % 64 != 0 or Cin % 64 != 0 or (Cout == 64 and Cin > 64 and R == 3) , f"{shape}: forward unexpectedly not served"
 
     # ---------- data gradient
-    if K.packed_supported(geom, BF, dgrad=True):
+    if stride == 1 and K.packed_supported(geom, BF, dgrad=True):
         dy = _q(torch.randn((N, Cout, P, Q), generator=g))
         add = _q(torch.randn((N, Cin, H, W), generator=g))
         mask = torch.rand((N, Cin, H, W), generator=g) > 0.4
@@ -128,7 +128,7 @@ def test_packed_fwd_and_dgrad(shape, dev):
 
 def test_packed_declines_what_it_does_not_serve(dev):
     assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 2, 1), BF)          # stride 2
-    assert not K.packed_supported(K.make_geom(2, 19, 19, 128, 64, 1, 1, 2, 0), BF, dgrad=True)      # strided 1x1 data gradient
+    assert not K.packed_supported(K.make_geom(2, 19, 19, 128, 64, 1, 1, 3, 0), BF, dgrad=True)      # 1x1 data gradient with stride 3
     assert not K.packed_supported(K.make_geom(2, 19, 19, 24, 128, 3, 3, 1, 1), BF)          # channels not a multiple of 64
     assert not K.packed_supported(K.make_geom(2, 19, 19, 64, 128, 3, 3, 1, 1), torch.float32)
     assert not K.packed_supported(K.make_geom(2, 1, 1, 64, 128, 3, 3, 1, 1), BF)            # 1x1 images (32x32 tiles at layer4)
@@ -136,3 +136,41 @@ def test_packed_declines_what_it_does_not_serve(dev):
     x = torch.zeros((2, 19, 19, 24), dtype=BF, device=dev)
     with pytest.raises(RuntimeError, match="not served"):
         K.conv_fwd_packed(geom, x, torch.zeros((16,), dtype=BF, device=dev))
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 41, 256, 128, 64), (3, 20, 20, 128, 256, 128), (64, 10, 10, 512, 1024, 256), (1, 7, 9, 64, 64, 64)])
+def test_compact_strided_gradient(shape, dev):
+    """The block input of a down-sampling bottleneck (model/resnet.py:183 + :51) receives two gradients: the stride-2 1x1 shortcut's
+    (non-zero at even pixels only) and the stride-1 conv1's.  The shortcut's data gradient is written in compact [N][P][Q][C] form and
+    conv1's data gradient adds it at the even pixels (add_stride = 2), masks and sums: the result must equal the dense computation."""
+    N, H, W, C, Ks, Kv = shape
+    g = torch.Generator().manual_seed(3 + H + C)
+    ws = _q(torch.randn((Ks, C, 1, 1), generator=g) / C ** 0.5)          # shortcut, stride 2
+    wv = _q(torch.randn((Kv, C, 1, 1), generator=g) / C ** 0.5)          # conv1, stride 1
+    gs = K.make_geom(N, H, W, C, Ks, 1, 1, 2, 0)
+    gv = K.make_geom(N, H, W, C, Kv, 1, 1, 1, 0)
+    assert K.packed_supported(gs, BF, dgrad=True) and K.packed_supported(gv, BF, dgrad=True)
+    dys = _q(torch.randn((N, Ks, gs.P, gs.Q), generator=g))
+    dyv = _q(torch.randn((N, Kv, H, W), generator=g))
+    mask = torch.rand((N, C, H, W), generator=g) > 0.4
+    ref_s = torch.nn.grad.conv2d_input((N, C, H, W), ws, dys, stride=2, padding=0)
+    ref_v = torch.nn.grad.conv2d_input((N, C, H, W), wv, dyv, stride=1, padding=0)
+    _, ws_chwk = K.weight_prep(ws.to(dev), None, BF, C, Ks, want_fwd=False, want_bwd=True)
+    _, wv_chwk = K.weight_prep(wv.to(dev), None, BF, C, Kv, want_fwd=False, want_bwd=True)
+    comp = K.conv_dgrad_packed(gs, _nhwc(dys, dev), K.pack_conv_weights(gs, ws_chwk, dgrad=True))
+    assert isinstance(comp, K.CompactGrad) and tuple(comp.t.shape) == (N, gs.P, gs.Q, C)
+    torch.cuda.synchronize()
+    assert _relerr(_from_nhwc(comp.t), ref_s[:, :, ::2, ::2]) < TOL
+    assert float(ref_s[:, :, 1::2, :].abs().max()) == 0.0 and float(ref_s[:, :, :, 1::2].abs().max()) == 0.0
+    dx, pc = K.conv_dgrad_packed(gv, _nhwc(dyv, dev), K.pack_conv_weights(gv, wv_chwk, dgrad=True), add=comp, mask_bits=_pack_bits(mask, dev),
+                                 want_colsum=True)
+    cs = pc.vector()
+    torch.cuda.synchronize()
+    # the compact operand was rounded to bf16 once more than the dense fp32 sum: same tolerance, relative to max|ref|
+    ref = (ref_v + _q(ref_s)) * mask
+    got = _from_nhwc(dx)
+    assert _relerr(got, ref) < TOL
+    assert bool((got[~mask] == 0).all())
+    assert _relerr(cs.cpu(), dx.float().sum(dim=(0, 1, 2)).cpu()) < 1e-3
+    with pytest.raises(ValueError, match="compact"):
+        K.conv_dgrad_packed(gs, _nhwc(dys, dev), K.pack_conv_weights(gs, ws_chwk, dgrad=True), mask_bits=_pack_bits(mask, dev))
