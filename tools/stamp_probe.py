@@ -48,17 +48,6 @@ for name in sys.argv[1:] or ["l1_3x3", "l2_3x3", "l3_3x3", "l4_3x3"]:
         tot = (b[:, 1] + b[:, 2] + b[:, 3] + b[:, 4])
         print(f"    total per workgroup med {tot.median():.0f} cycles")
         continue
-    if float(b[:, 0].max()) == 1.0:           # persistent kernel: per-phase sums over the workgroup's tiles
-        nt = b[:, 5]
-        print(f"{name}: waves {len(b)}, tiles per workgroup med {nt.median():.0f} (min {nt.min():.0f}, max {nt.max():.0f}); per tile (cycles):")
-        names_ = ["wait for the tile + barrier", "zero + MFMA + read-out barrier", "issue next tile", "last MFMAs + epilogue"]
-        if os.environ.get("EPI"):
-            names_ = ["epilogue: arithmetic -> packed", "epilogue: 2 row stores", "epilogue: bit word + store", "epilogue: re-arm next operands"]
-        for n_, col in zip(names_, (1, 2, 3, 4)):
-            v = b[:, col] / nt
-            print(f"    {n_:32s} med {v.median():8.0f}   p10 {v.quantile(0.1):8.0f}   p90 {v.quantile(0.9):8.0f}")
-        print(f"    total per tile med {((b[:, 1] + b[:, 2] + b[:, 3] + b[:, 4]) / nt).median():.0f}")
-        continue
     d = [b[:, i + 1] - b[:, i] for i in range(5)]
     ncc = C // 64
     ideal = ncc * R * R * 16 * 32
