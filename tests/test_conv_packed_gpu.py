@@ -174,3 +174,29 @@ def test_compact_strided_gradient(shape, dev):
     assert _relerr(cs.cpu(), dx.float().sum(dim=(0, 1, 2)).cpu()) < 1e-3
     with pytest.raises(ValueError, match="compact"):
         K.conv_dgrad_packed(gs, _nhwc(dys, dev), K.pack_conv_weights(gs, ws_chwk, dgrad=True), mask_bits=_pack_bits(mask, dev))
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 3), (64, 256, 1), (256, 128, 3), (512, 2048, 1), (64, 64, 3)])
+def test_one_launch_staging_writes_the_packed_operands_bit_exactly(shape, dev):
+    """cs_stage_conv_bn_multi (LDS-tiled path for unpadded packed layers) against the two-step route: fold + stage with
+    cs_stage_conv_bn, then cs_pack_conv_weights -- the same arithmetic, so the packed operands must be identical bit for bit."""
+    Kc, C, R = shape
+    torch.manual_seed(Kc + C + R)
+    conv = torch.nn.Conv2d(C, Kc, R, 1, R // 2, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(Kc).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    pack = K.StagePack([(conv, bn, C, Kc, True, True, True), (conv, bn, C, Kc, True, False, False)], BF)
+    pack.launch()
+    w_f, w_b, scale, shift, rstd = pack.staged[0]
+    u_f, u_b = pack.staged[1][:2]                                      # the plain [k][tap][c] / [c][tap][k] operands of the same layer
+    geom = K.make_geom(2, 19, 19, C, Kc, R, R, 1, R // 2)
+    scale_ref = bn.weight.detach() * (1.0 / torch.sqrt(bn.running_var + bn.eps))          # the kernels' own expression
+    w_khwc, w_chwk = K.weight_prep(conv.weight.detach(), scale_ref, BF, C, Kc, want_fwd=True, want_bwd=True)
+    ref_f = K.pack_conv_weights(geom, w_khwc, dgrad=False)
+    ref_b = K.pack_conv_weights(geom, w_chwk, dgrad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(w_f.view(-1).view(torch.int16), ref_f.view(-1).view(torch.int16)[: w_f.numel()])
+    assert torch.equal(w_b.view(-1).view(torch.int16), ref_b.view(-1).view(torch.int16)[: w_b.numel()])
+    assert float((scale - scale_ref).abs().max()) < 1e-6
+    assert torch.equal(u_f.view(torch.int16), w_khwc.view(torch.int16)) and torch.equal(u_b.view(torch.int16), w_chwk.view(torch.int16))
