@@ -45,6 +45,7 @@ struct C2Params {
     int DH, DW, NOUT;
     int Wp, Hp, PW, PH;            // padded-linear geometry of the source: Wp = SW + PW, Hp = SH + PH
     int stride;                    // 1x1 kernel only
+    int gather, GH, GWp;           // ring forward of the pixel-paired stem (cs_stem_fwd_packed): LDS row = 32 gathered 16-byte (kh, pair) slots
     int add_stride, AH, AW;        // ring data gradient: the add operand is a COMPACT [NS][AH][AW][NOUT] tensor that only exists at destination
                                    // pixels (add_stride * y, add_stride * x) -- the gradient a strided 1x1 shortcut sends to the block input
     unsigned mg_dw, sh_dw, mg_dh, sh_dh, mg_wp, sh_wp, mg_hp, sh_hp;
@@ -93,6 +94,19 @@ __device__ __forceinline__ void dma_block(const i32x4& rsrc, unsigned lds_dst, u
         "buffer_load_dwordx4 %2, %3, %0 offen lds"
         : "=&s"(tmp)
         : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+        : "scc");
+}
+
+// the same with an independent offset per piece (gathered operand rows: each 16-byte column of a row comes from another source pixel)
+__device__ __forceinline__ void dma_block2(const i32x4& rsrc, unsigned lds_dst, unsigned voff_a, unsigned voff_b) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+        "s_add_u32 m0, %0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds"
+        ::"s"(lds_dst), "v"(voff_a), "v"(voff_b), "s"(rsrc)
         : "scc");
 }
 
@@ -847,7 +861,8 @@ template <int TM, bool DG> struct RingEpilogue {
     }
 };
 
-template <int TM, int WM, int WN, bool DG>
+// GA: gathered operand rows (the pixel-paired stem, cs_stem_fwd_packed); a template flag because its per-tile state costs registers
+template <int TM, int WM, int WN, bool DG, bool GA = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void conv2_ring_kernel(C2Params p, int n_groups) {
     static_assert(WM * WN == 4 && WM * TM == 4, "a ring slot holds 128 pixel rows");
     constexpr int BM = 128, BN = WN * 32;
@@ -882,10 +897,23 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
     const unsigned w_base = (unsigned)(n_w >> 5) * (unsigned)NCC * 4096u;
 
     // this wave's two 16-row blocks (wave, wave + 4) of pixel tile mt: byte offset of (row, chunk column) or out of range
+    // gathered rows (the pixel-paired stem: 7 x 4 taps of 16 bytes, stride 2 rows / 1 pair, pad 3 rows / 2 pairs): per block the byte
+    // base of the row's image (~0: no such row) and its first tap's source row / pair; slot (kh, pw) adds (kh * GWp + pw) * 16 bytes
+    int f_gy[2] = {0, 0}, f_gx[2] = {0, 0};
     auto tile_voff = [&](unsigned mt, unsigned (&vo)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const unsigned m = mt * BM + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+            if constexpr (GA) {
+                const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+                const unsigned x = m - yall * (unsigned)p.DW;
+                const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+                const unsigned y = yall - n * (unsigned)p.DH;
+                vo[j] = (m < p.M && mt != 0xffffffffu) ? n * (unsigned)(p.GH * p.GWp) * 16u : 0xffffffffu;
+                f_gy[j] = 2 * (int)y - 3;
+                f_gx[j] = (int)x - 2;
+                continue;
+            }
             unsigned pix = m;
             if (p.stride > 1) {
                 const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
@@ -926,6 +954,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
     };
     auto issue_a = [&]() {
         const unsigned dst = smem_base + f_slot * SLOT;
+        if constexpr (GA) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                auto slot_off = [&](int sl) -> unsigned {
+                    const int kh = sl >> 2, pw = sl & 3;
+                    const int iy = f_gy[j] + kh, px = f_gx[j] + pw;
+                    const bool ok = f_vo[j] != 0xffffffffu && sl < 28 && (unsigned)iy < (unsigned)p.GH && (unsigned)px < (unsigned)p.GWp;
+                    return ok ? f_vo[j] + (unsigned)(iy * p.GWp + px) * 16u : OOB;
+                };
+                const int s0 = f_c * 8 + (lane >> 4);
+                dma_block2(rsrc_a, dst + (unsigned)(wave + 4 * j) * 2048u, slot_off(s0), slot_off(s0 + 4));
+            }
+            return;
+        }
         dma_block(rsrc_a, dst + (unsigned)wave * 2048u, f_vo[0], (unsigned)f_c * 128u);
         dma_block(rsrc_a, dst + (unsigned)(wave + 4) * 2048u, f_vo[1], (unsigned)f_c * 128u);
     };
@@ -1199,6 +1241,19 @@ int launch_ring_t(const C2Params& p, hipStream_t st) {
         if (cost <= best_cost) { best_cost = cost; best = g; }
     }
     const size_t lds = 3 * 16384 + 4 * (size_t)TM * 2048;
+    if constexpr (TM == 2 && !DG) {
+        if (p.gather) {
+            if (!allow_lds(conv2_ring_kernel<TM, WM, WN, DG, true>, lds)) return CS_ERR_LAUNCH;
+            cs_set_variant_("conv2_ring_kernel<2,2,2,false,true>");
+            hipLaunchKernelGGL((conv2_ring_kernel<TM, WM, WN, DG, true>), dim3(best * (unsigned)p.n_ntiles), dim3(256), lds, st, p, (int)best);
+            CS_LAUNCH_CHECK();
+            return CS_OK;
+        }
+    }
+    if (p.gather) {
+        cs_set_error_("conv2: gathered operand rows are served for 64 output channels only");
+        return CS_ERR_UNSUPPORTED;
+    }
     if (!allow_lds(conv2_ring_kernel<TM, WM, WN, DG>, lds)) return CS_ERR_LAUNCH;
     char name[64];
     snprintf(name, sizeof(name), "conv2_ring_kernel<%d,%d,%d,%s>", TM, WM, WN, DG ? "true" : "false");
@@ -1351,4 +1406,39 @@ extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const
     pl.p.dbg = g_dbg_buf;
 #endif
     return launch_any(pl, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+// Forward of the pixel-paired 7x7 / stride-2 stem (model/resnet.py:171, csrc/conv_igemm.hip cs_stem_*) on the ring kernel: the LDS row of
+// an output pixel is GATHERED -- 32 slots of 16 bytes, slot (kh, pw) = pair (x - 2 + pw) of source row (2y - 3 + kh), slots 28..31 zero --
+// and multiplied by the packed [K][256] weights (w_pair padded with one zero filter row, cs_pack_conv_weights of the 1x1 geometry
+// C = 256).  x_pair: [N][H][(W+1)/2][8] bf16 (cs_stem_pair_input); y: [N][P][Q][K], P = (H - 1) / 2 + 1.
+extern "C" int cs_stem_fwd_packed(int N, int H, int W, int K, const void* x_pair, const void* w_packed, const float* shift, int act, void* y,
+                                  uint8_t* positive_bits, void* stream) {
+    CS_CHECK_ARG(x_pair && w_packed && y && N > 0 && H >= 7 && W >= 7, "stem_fwd_packed: bad arguments");
+    CS_CHECK_ARG(K == 64, "stem_fwd_packed: 64 output channels (the stem of every ResNet / ResNeXt of model/resnet.py)");
+    CS_CHECK_ARG(act == CS_ACT_NONE || act == CS_ACT_RELU, "stem_fwd_packed: activation must be none or ReLU");
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Wh = (W + 1) / 2;
+    const long long M = (long long)N * P * Q;
+    const unsigned long long src_bytes = (unsigned long long)N * H * Wh * 16ull;
+    CS_CHECK_ARG(P >= 2 && Q >= 2 && M < (1ll << 31) - 512 && src_bytes < 0x80000000ull, "stem_fwd_packed: extents out of range");
+    C2Plan pl;
+    C2Params& p = pl.p;
+    p = C2Params{};
+    p.SH = H; p.SW = Wh; p.SC = 256; p.NS = N;
+    p.DH = P; p.DW = Q; p.NOUT = K;
+    p.stride = 1; p.add_stride = 1;
+    p.gather = 1; p.GH = H; p.GWp = Wh;
+    magic((unsigned)Q, p.mg_dw, p.sh_dw);
+    magic((unsigned)P, p.mg_dh, p.sh_dh);
+    p.NCC = 4;
+    p.M = (unsigned)M;
+    p.src_bytes = (unsigned)src_bytes;
+    p.pix_bytes = 16u;
+    p.wpk_bytes = (unsigned)(cs_ceil_div(K, 32) * 32 * 256 * 2);
+    pl.cfg = K == 64 ? 7 : 6;
+    p.n_ntiles = cs_ceil_div(K, K == 64 ? 64 : 128);
+    pl.nbw = 0; pl.ncc = 4; pl.rows = 0;
+    p.src = x_pair; p.wpk = w_packed; p.dst = y;
+    p.shift = shift; p.act = act; p.bits_out = positive_bits;
+    return launch_gemm<false>(pl, reinterpret_cast<hipStream_t>(stream));
 }

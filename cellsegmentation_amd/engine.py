@@ -344,7 +344,9 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             xp = K.stem_pair_input(x) if stem else None
             wp = K.stem_pair_weights(st.w_khwc) if stem else None
             if not batch_stats:
-                if stem:
+                if stem and PACKED and K.stem_fwd_packed_supported(geom, dtype):
+                    y = K.stem_fwd_packed(geom, xp, K.stem_pack_weights(wp), st.shift, u.act)       # ring kernel, gathered rows
+                elif stem:
                     y = K.stem_fwd(geom, xp, wp, None, st.shift, u.act)
                 elif getattr(st, "fwd_packed", False):
                     if save and RELU_BITS and u.act == ACT_RELU:

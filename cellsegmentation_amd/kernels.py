@@ -358,6 +358,30 @@ def stem_fwd(geom, x_pair, w_pair, scale=None, shift=None, act=CS_ACT_NONE, stat
     return y
 
 
+def stem_pack_weights(w_pair):
+    """paired stem weights [K][7][4][8] bf16 -> the packed operand of stem_fwd_packed: one zero filter row appended ([K][256]) and
+    re-ordered like a 1x1 convolution's forward weights."""
+    K_ = w_pair.shape[0]
+    w256 = torch.zeros((K_, 1, 1, 256), dtype=w_pair.dtype, device=w_pair.device)
+    w256.view(K_, 256)[:, :224] = w_pair.reshape(K_, 224)
+    return pack_conv_weights(make_geom(1, 2, 2, 256, K_, 1, 1, 1, 0), w256, dgrad=False)
+
+
+def stem_fwd_packed_supported(geom, dtype):
+    return dtype == torch.bfloat16 and is_stem_geom(geom) and geom.K == 64 and geom.P >= 2 and geom.Q >= 2
+
+
+def stem_fwd_packed(geom, x_pair, w_packed, shift=None, act=CS_ACT_NONE, want_bits=False):
+    """The stem forward on the ring kernel (bf16): y, or (y, bits)."""
+    y = torch.empty((geom.N, geom.P, geom.Q, geom.K), dtype=x_pair.dtype, device=x_pair.device)
+    bits = torch.empty((geom.N, geom.P, geom.Q, geom.K // 8), dtype=torch.uint8, device=x_pair.device) if want_bits else None
+    lib = _lib.load()
+    _lib.check(_timed("fwd", geom, x_pair.dtype, lambda: lib.cs_stem_fwd_packed(
+        geom.N, geom.H, geom.W, geom.K, _p(x_pair), _p(w_packed), _p(shift), act, _p(y), _p(bits), _stream()),
+        extra_tensors=1.0 / 16 if want_bits else 0), "stem_fwd_packed")
+    return (y, bits) if want_bits else y
+
+
 def stem_wgrad(geom, x_pair, dy, use_tr_read=True):
     """Raw weight gradient of the stem in the ORDINARY slab layout [1, K, 7, 7, 8] (one slab: the paired split-K slabs are summed
     while they are un-paired), ready for wgrad_finalize / wgrad_finalize_batched."""

@@ -348,6 +348,10 @@ int cs_stem_pair_input(const void* x_nhwc8, int dtype, int N, int H, int W, void
 int cs_stem_pair_weights(const void* w_khwc, int dtype, int K, void* w_pair, void* stream);
 int cs_stem_fwd(int N, int H, int W, int K, int dtype, const void* x_pair, const void* w_pair, const float* scale, const float* shift,
                 int act, void* y, double* stats, void* workspace, void* stream);
+/* bf16 forward on the ring kernel of conv_v2.hip (gathered operand rows): w_packed = cs_pack_conv_weights of the 1x1 geometry
+ * (C = 256, K) applied to w_pair padded to [K][8][4][8] with one zero filter row; epilogue as cs_conv2d_fwd_packed. */
+int cs_stem_fwd_packed(int N, int H, int W, int K, const void* x_pair, const void* w_packed, const float* shift, int act, void* y,
+                       uint8_t* positive_bits, void* stream);
 int cs_stem_wgrad_splits(int N, int H, int W, int K);
 int cs_stem_wgrad(int N, int H, int W, int K, int dtype, const void* x_pair, const void* dy, float* dw_pair_slabs, int use_tr_read,
                   void* stream);

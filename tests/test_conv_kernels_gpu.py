@@ -208,6 +208,15 @@ def test_paired_stem_equals_the_generic_7x7_path(dev, dtype, hw):
     y = K.stem_fwd(g, xp, wp, None, shift, K.CS_ACT_RELU)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert float((y.float() - y_ref.float()).abs().max()) <= tol * max(1.0, float(y_ref.float().abs().max()))
+    if dtype == torch.bfloat16:
+        # the same forward on the ring kernel of conv_v2.hip (gathered operand rows, packed [K][256] weights), with sign bits
+        assert K.stem_fwd_packed_supported(g, dtype)
+        y2, bits = K.stem_fwd_packed(g, xp, K.stem_pack_weights(wp), shift, K.CS_ACT_RELU, want_bits=True)
+        torch.cuda.synchronize()
+        assert float((y2.float() - y_ref.float()).abs().max()) <= tol * max(1.0, float(y_ref.float().abs().max()))
+        sh = torch.arange(8, dtype=torch.uint8, device=dev)
+        got_bits = ((bits.unsqueeze(-1) >> sh) & 1).bool().reshape(N, g.P, g.Q, Kc)
+        assert torch.equal(got_bits, y2 > 0)
     # batch statistics through the same entry point
     st_ref, st = K.new_stats(Kc, dev), K.new_stats(Kc, dev)
     K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_NONE, stats=st_ref)
