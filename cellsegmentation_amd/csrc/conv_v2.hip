@@ -1256,7 +1256,7 @@ int launch_ring_t(const C2Params& p, hipStream_t st) {
     }
     if (!allow_lds(conv2_ring_kernel<TM, WM, WN, DG>, lds)) return CS_ERR_LAUNCH;
     char name[64];
-    snprintf(name, sizeof(name), "conv2_ring_kernel<%d,%d,%d,%s>", TM, WM, WN, DG ? "true" : "false");
+    snprintf(name, sizeof(name), "conv2_ring_kernel<%d,%d,%d,%s,false>", TM, WM, WN, DG ? "true" : "false");
     cs_set_variant_(name);
     hipLaunchKernelGGL((conv2_ring_kernel<TM, WM, WN, DG>), dim3(best * (unsigned)p.n_ntiles), dim3(256), lds, st, p, (int)best);
     CS_LAUNCH_CHECK();
