@@ -230,6 +230,37 @@ def cpu_baseline(micro=16, accum=4, steps=3):
             "s_per_step": round(t, 3)}
 
 
+def cpu_baseline_c1(steps=5):
+    """BASELINE.json configs[0] on the host cores: the ResNet-18 image counter step (batch 8, CE + MSE, BN train, Adam) through the
+    oracle -- the reference's own CPU-runnable case, timed for tools/bench_configs.py's `c1cpu` line (part of the cpu_baseline leg:
+    the only place outside tests/ and smoke() that may run the oracle)."""
+    from oracle import cellseg_oracle as orc
+    model_name, cores = _host_cpu()
+    torch.set_num_threads(cores)
+    xc = synth.normalise(synth.ihc_tiles(8, 299, 1234))
+    cnt = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230]).float()
+    cl = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6])
+    sd = orc.empty_state_dict("resnet18")
+    synth.fill_state_dict(sd)
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith(("fc_tile", "upconv", "seg_out")):
+            v.requires_grad_()
+            params.append(v)
+    opt = torch.optim.Adam(params, lr=8e-5, weight_decay=1e-4)
+    orc.image_step_loss(sd, xc, cl, cnt, "resnet18")[2].backward()
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        orc.image_step_loss(sd, xc, cl, cnt, "resnet18")[2].backward()
+        opt.step()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {"value": round(8 / t, 2), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": model_name,
+            "sample": f"ResNet-18 image counter B=8 fp32, median of {steps} steps", "s_per_step": round(t, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

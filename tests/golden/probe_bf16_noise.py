@@ -5,12 +5,12 @@ the GPU, ATen/MIOpen kernels driven by the oracle's functional restatement)?  Pr
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cellsegmentation_amd import synth, functional as HF
 from cellsegmentation_amd.model import resnet as R
 from oracle import cellseg_oracle as orc
 
-GOLD = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "reference_vectors.npz"))
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.npz"))
 dev = torch.device("cuda:0")
 tag = "resnet50/tile299"
 n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])

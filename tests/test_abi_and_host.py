@@ -130,3 +130,29 @@ def test_get_tiles_host_grid_matches_reference_known_answer():
     assert tiles.get_tiles((64, 64), 32, 32) == [(0, 0), (0, 32), (32, 0), (32, 32)]     # stride lands on the border: no extra tile
     ti, rc = tiles.tile_index(2, (64, 64), 32, 32)
     assert ti.tolist() == [0] * 4 + [1] * 4 and rc.shape == (8, 2)
+
+
+def test_the_oracle_stays_test_infrastructure():
+    """oracle/ may be imported by tests/, by smoke() (cellsegmentation_amd/smoke.py, called from __graft_entry__.smoke) and by
+    bench.py's cpu_baseline leg only: the product path must never route through it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    allowed = {os.path.join("cellsegmentation_amd", "smoke.py"), "bench.py"}
+    offenders = []
+    for base, dirs, files in os.walk(root):
+        rel = os.path.relpath(base, root)
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__", "oracle", "tests")]
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.normpath(os.path.join(rel, f))
+            text = open(os.path.join(base, f)).read()
+            if re.search(r"^\s*(from\s+oracle\b|import\s+oracle\b)", text, re.M) and path not in allowed:
+                offenders.append(path)
+    assert not offenders, offenders
+    # ... and inside bench.py only the cpu_baseline functions do
+    src = open(os.path.join(root, "bench.py")).read()
+    for m in re.finditer(r"^\s*from oracle import", src, re.M):
+        head = src[:m.start()]
+        fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
+        assert fn.startswith("cpu_baseline"), fn

@@ -126,30 +126,9 @@ if "c5x" in which:
         opt.step()
     run("c5x resnet50 segment B=4 512x512 bf16 (decoder training, Dice)", s5x, 4, "images/s")
 if "c1cpu" in which:
-    # test infrastructure only: the oracle is the CPU restatement of the reference (oracle/cellseg_oracle.py), timed as a baseline
+    # the oracle is test infrastructure: it runs inside bench.py's cpu_baseline leg only
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import _host_cpu
-    from oracle import cellseg_oracle as orc
-    model_name, cores = _host_cpu()
-    torch.set_num_threads(cores)
-    xc = synth.normalise(synth.ihc_tiles(8, 299, 1234))
-    cnt = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230]).float(); cl = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6])
-    sd = orc.empty_state_dict("resnet18")
-    synth.fill_state_dict(sd)
-    params = []
-    for k, v in sd.items():
-        if v.is_floating_point() and "running" not in k and not k.startswith(("fc_tile", "upconv", "seg_out")):
-            v.requires_grad_()
-            params.append(v)
-    optc = torch.optim.Adam(params, lr=8e-5, weight_decay=1e-4)
-    orc.image_step_loss(sd, xc, cl, cnt, "resnet18")[2].backward()
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        optc.zero_grad()
-        orc.image_step_loss(sd, xc, cl, cnt, "resnet18")[2].backward()
-        optc.step()
-        ts.append(time.perf_counter() - t0)
-    t = sorted(ts)[len(ts) // 2]
-    print(json.dumps({"config": f"c1cpu resnet18 image counter B=8 fp32 on {cores} host cores ({model_name}), oracle port, median of 5",
-                      "value": round(8 / t, 2), "unit": "images/s", "ms_per_step": round(t * 1e3, 1)}), flush=True)
+    from bench import cpu_baseline_c1
+    r = cpu_baseline_c1()
+    print(json.dumps({"config": f"c1cpu resnet18 image counter B=8 fp32 on {r['cores']} host cores ({r['cpu_model']}), oracle port, median of 5",
+                      "value": r["value"], "unit": "images/s", "ms_per_step": round(r["s_per_step"] * 1e3, 1)}), flush=True)
