@@ -134,6 +134,10 @@ def load():
         raise CellsegLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C cellsegmentation_amd/csrc`). There is no CPU fallback for the HIP hot path.")
+    # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64, and both libraries must share ONE HIP runtime (streams,
+    # device pointers).  Loaded the other way round, this library pulls /opt/rocm's runtime in first and torch's device queries then
+    # fail with "no ROCm-capable device is detected" (seen when build() and smoke() ran in one process).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, intentionally fatal
