@@ -223,7 +223,9 @@ def _stage_weights(u, dtype, Cp, Kp, need_bwd, folded, training, geom=None, pkf=
     cache invalid, because tensor version counters cannot be trusted to see the update -- torch's fused optimizers
     (`Adam(fused=True)`) write the parameters without bumping `_version`."""
     conv, bn = u.conv, u.bn
-    key_t = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+    # (a batch-statistics pass folds nothing of the BatchNorm into the operands: they depend on the convolution's own tensors only, so a
+    # frozen encoder under train-mode BN -- the segmentation stage -- stages once, not once per step)
+    key_t = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if (bn is not None and folded) else [])
     key = (_STAGE_EPOCH[0], dtype, Cp, Kp, need_bwd, folded, pkf, pkb) + tuple((t._version, t.data_ptr()) if t is not None else None for t in key_t)
     if training and any(t is not None and t.requires_grad for t in key_t):
         key = None
@@ -327,8 +329,8 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             # A pass that will be followed by an optimizer step, or that updates BN running statistics in place, must not leave
             # a version-keyed cache behind: fused optimizers and our own kernels write those tensors without bumping `_version`
             # (a later no-grad pass would be served the old weights; the one-launch pack path below never touches `_cache`)
-            if (save and any(p_ is not None and p_.requires_grad for p_ in (conv.weight, conv.bias) + ((u.bn.weight, u.bn.bias) if u.bn is not None else ()))) \
-                    or batch_stats:
+            if save and any(p_ is not None and p_.requires_grad
+                            for p_ in (conv.weight, conv.bias) + ((u.bn.weight, u.bn.bias) if (u.bn is not None and not batch_stats) else ())):
                 u._cache = None
             if pre is not None and pre[0] == (Cp, Kp, need_bwd, pkf, pkb) and not batch_stats:
                 st = pre[1]
