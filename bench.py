@@ -130,8 +130,10 @@ def roofline_from(records, steps, dtype):
             achieved, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         else:
             achieved, peak, unit, bound = fl / (ms * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
+        tr = _traffic_for(name, by / n)
+        # `traffic`: HBM bytes per launch from the PMC passes (a plain number, or null); the read / write split rides beside it
         return {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-                "traffic": _traffic_for(name, by / n), "kernel": name, "avg_launch_ms": round(ms / n, 4), "launches": n,
+                "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_detail": tr, "kernel": name, "avg_launch_ms": round(ms / n, 4), "launches": n,
                 "share_of_conv_time": round(ms / sum(v[1] for v in per_kernel.values()), 4),
                 "algorithmic_per_launch": {"gflop": round(fl / n / 1e9, 3), "mbytes": round(by / n / 1e6, 2), "flop_per_byte": round(fl / by, 1)}}
 
