@@ -444,7 +444,10 @@ static void dw_wgrad_split(const CsConvGeom* g, int& rows_per_block, unsigned& n
     static const int dw_target = [] { const char* e = getenv("CELLSEG_DW_BLOCKS"); return e ? atoi(e) : 1024; }();   // A/B experiments only
     long long slabs = dw_target / chunks;
     if (slabs < 1) slabs = 1;
-    if (slabs > 256) slabs = 256;
+    // every slab is one fp32 partial row of R*R*C floats for the fold: at most 32 MiB of them, at least 256
+    long long cap = (32ll << 20) / ((long long)g->R * g->R * g->C * 4);
+    if (cap < 256) cap = 256;
+    if (slabs > cap) slabs = cap;
     long long rpb = (rows + slabs - 1) / slabs;
     const long long min_rows = (64 + g->Q - 1) / g->Q;           // >= 64 pixels per workgroup
     if (rpb < min_rows) rpb = min_rows;
