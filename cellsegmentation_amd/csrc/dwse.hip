@@ -392,7 +392,8 @@ static int dw_stats_grid(const CsConvGeom* g) {
     while (b) { const int t = a % b; a = b; b = t; }           // gcd(CG, 256)
     const int m = CG / a;                                      // workgroup-count granule
     long long want = ((long long)g->N * g->P * g->Q * CG + 255) / 256;
-    if (want > 1024) want = 1024;
+    static const int cap = [] { const char* e = getenv("CELLSEG_DW_STATS_BLOCKS"); return e ? atoi(e) : 1024; }();     // A/B experiments only
+    if (want > cap) want = cap;
     long long grid = (want + m - 1) / m * m;
     if (grid < m) grid = m;
     return (int)grid;
