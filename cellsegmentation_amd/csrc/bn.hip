@@ -254,14 +254,16 @@ inline int fold_partial(const double* partial, int blocks, int C, double* out, h
 }
 
 inline int rows_per_block_for(long long M) {
-    long long r = (M + 1023) / 1024;
+    static const int target = [] { const char* e = getenv("CELLSEG_BN_BLOCKS"); return e ? atoi(e) : 1024; }();     // A/B experiments only
+    long long r = (M + target - 1) / target;
     if (r < 64) r = 64;
     return (int)r;
 }
 
 inline int grid_ew(long long total) {
+    static const int cap = [] { const char* e = getenv("CELLSEG_EW_BLOCKS"); return e ? atoi(e) : 16384; }();        // A/B experiments only
     long long b = (total + 255) / 256;
-    if (b > 16384) b = 16384;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
