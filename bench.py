@@ -18,7 +18,40 @@ import os
 import sys
 import time
 
-import torch
+
+def _self_launch():
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: start N ranks ourselves, as a FRESH child process
+    (`python -m torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1) and exit with its return code.  This runs
+    before torch / the HIP library are imported, so the parent never touches the GPU (no exec after GPU init, no second HIP
+    context beside the ranks).  The reference's counterpart is the DDP stub of train_tile.py:227-238."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr=127.0.0.1",
+           f"--master-port={port}", os.path.abspath(__file__), *argv]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -280,6 +313,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (it starts "
+                         f"the N ranks itself) or under torchrun with --nproc-per-node equal to --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     n_dev = torch.cuda.device_count()

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "cs_linear_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cs_softmax_ce": (c_int, [_P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "cs_softmax_prob1": (c_int, [_P, _P, c_int, c_int, _P]),
+    "cs_softmax_argmax": (c_int, [_P, _P, c_int, c_int, _P]),
     "cs_mse": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P]),
     "cs_bn_stats": (c_int, [_P, c_int, c_longlong, c_int, _P, _P, _P]),
     "cs_bn_partial_workspace": (c_size_t, [c_longlong, c_int]),

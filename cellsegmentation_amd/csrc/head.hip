@@ -119,6 +119,25 @@ __global__ void softmax_prob1_kernel(const float* __restrict__ logits, float* __
     p1[m] = expf(r[1] - mx) / se;
 }
 
+// inference.py:72-76,118-119: np.argmax(F.softmax(logits, 1), axis=1) -- the arg max is taken over the fp32 PROBABILITIES (two logits
+// closer than the rounding of exp / the division tie as probabilities and the first index wins), not over the logits.
+__global__ void softmax_argmax_kernel(const float* __restrict__ logits, long long* __restrict__ idx, int M, int C) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* r = logits + (long long)m * C;
+    float mx = r[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(r[c] - mx);
+    float best = expf(r[0] - mx) / se;
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+        const float pc = expf(r[c] - mx) / se;
+        if (pc > best) { best = pc; bi = c; }
+    }
+    idx[m] = bi;
+}
+
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, int weighted,
                                                   float inv, float* __restrict__ loss, float* __restrict__ dx, int M) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,6 +280,14 @@ extern "C" int cs_softmax_prob1(const float* logits, float* p1, int M, int C, vo
     CS_CHECK_ARG(logits && p1 && M > 0 && C > 1, "softmax_prob1: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(softmax_prob1_kernel, dim3((M + 255) / 256), dim3(256), 0, st, logits, p1, M, C);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_softmax_argmax(const float* logits, int64_t* idx, int M, int C, void* stream) {
+    CS_CHECK_ARG(logits && idx && M > 0 && C > 0, "softmax_argmax: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3((M + 255) / 256), dim3(256), 0, st, logits, reinterpret_cast<long long*>(idx), M, C);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

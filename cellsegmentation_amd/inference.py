@@ -87,7 +87,7 @@ def inference_image(loader, model, device, epoch=None, total_epochs=None, mode='
                 batch_ids, data = data
                 ids.append(np.asarray(batch_ids))
             output = model(data.to(device))
-            cat_labels = torch.argmax(output[0], dim=1).cpu().numpy()        # argmax of softmax == argmax of logits
+            cat_labels = K.softmax_argmax(output[0].float().contiguous()).cpu().numpy()      # argmax of the PROBABILITIES (:72-76)
             output_reg = np.round(output[1][:, 0].cpu().numpy()).astype(int)
             if cls_limit:
                 for j, x in enumerate(output_reg):
@@ -113,7 +113,7 @@ def inference_image_cls(loader, model, device, epoch=None, total_epochs=None, mo
             if mode == 'train':
                 data = data[0]
             output = model(data.to(device))
-            cats.append(torch.argmax(output[0], dim=1).cpu().numpy().astype(np.float64))     # argmax of softmax == argmax of logits
+            cats.append(K.softmax_argmax(output[0].float().contiguous()).cpu().numpy().astype(np.float64))     # :118-119
     return np.concatenate(cats) if cats else np.array(())
 
 

@@ -794,6 +794,14 @@ def softmax_prob1(logits):
     return p1
 
 
+def softmax_argmax(logits):
+    """np.argmax(F.softmax(logits, 1), axis=1) of inference.py:72-76 on the device: int64 [M], first index on probability ties."""
+    M, C = logits.shape
+    idx = torch.empty((M,), dtype=torch.int64, device=logits.device)
+    _lib.check(_lib.load().cs_softmax_argmax(_p(logits), _p(idx), M, C, _stream()), "softmax_argmax")
+    return idx
+
+
 def mse(x, t, weighted=False, mean=True, want_grad=True):
     M = x.numel()
     loss = torch.empty((1,), dtype=torch.float32, device=x.device)

@@ -281,6 +281,9 @@ int cs_softmax_ce(const float* logits, const int64_t* labels, float gamma, float
                   void* stream);
 /* softmax(logits,1)[:,1] (inference.py:24-27) */
 int cs_softmax_prob1(const float* logits, float* p1, int M, int C, void* stream);
+/* np.argmax(F.softmax(logits,1), axis=1) (inference.py:72-76, 118-119): arg max over the fp32 probabilities, first index on
+ * ties (logits closer than the rounding of exp/÷ tie as probabilities); idx int64 [M]. */
+int cs_softmax_argmax(const float* logits, int64_t* idx, int M, int C, void* stream);
 /* sum or mean of w_i*(x_i-t_i)^2, w_i = 1 (weighted==0) or the reference's weighted_mse weights
  * (metrics/metrics.py:23-33: ln(t) if t>=20 else t).  dx nullable. scale = upstream grad factor. */
 int cs_mse(const float* x, const float* t, int weighted, int mean, float* loss, float* dx, int M, void* stream);

@@ -60,6 +60,25 @@ def test_gap_avgmax(dtype, dev):
     assert float((_nchw(dxm) - x.grad * (x.detach() > 0)).abs().max()) < tol
 
 
+def test_softmax_argmax_takes_the_arg_max_of_the_probabilities(dev):
+    """inference.py:72-76 / :118-119 do np.argmax(F.softmax(logits, 1), axis=1): index work, bit-exact.  Two logits one ulp apart
+    tie as fp32 probabilities (exp of -7e-9 rounds to 1.0f) and np.argmax then returns the FIRST index, whereas the arg max of
+    the logits returns the larger one ('What's weak')."""
+    torch.manual_seed(2)
+    lo = torch.randn(300, 7)
+    a = torch.tensor(0.1)
+    b = torch.nextafter(a, torch.tensor(1.0))
+    lo[0] = torch.tensor([-3.0, a, b, -1.0, -2.0, -5.0, -4.0])            # larger logit second -> probabilities tie -> index 1
+    lo[1] = torch.tensor([b, -3.0, a, -1.0, -2.0, -5.0, -4.0])            # larger logit first
+    lo[2] = torch.tensor([-1.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0])      # all equal -> 0
+    ref = np.argmax(F.softmax(lo, dim=1).detach().clone().cpu(), axis=1)
+    ref = np.asarray(ref)
+    got = K.softmax_argmax(lo.to(dev)).cpu().numpy()
+    assert got.dtype == np.int64
+    assert int(ref[0]) == 1 and int(torch.argmax(lo[0])) == 2             # the case the logits arg max gets wrong
+    assert np.array_equal(got, ref)
+
+
 def test_linear_ce_mse(dev):
     torch.manual_seed(11)
     M, Kf, N = 9, 515, 7
