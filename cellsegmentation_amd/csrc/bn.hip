@@ -254,14 +254,14 @@ inline int fold_partial(const double* partial, int blocks, int C, double* out, h
 }
 
 inline int rows_per_block_for(long long M) {
-    static const int target = [] { const char* e = getenv("CELLSEG_BN_BLOCKS"); return e ? atoi(e) : 1024; }();     // A/B experiments only
+    static const int target = cs_env_int_("CELLSEG_BN_BLOCKS", 1024);     // A/B experiments only
     long long r = (M + target - 1) / target;
     if (r < 64) r = 64;
     return (int)r;
 }
 
 inline int grid_ew(long long total) {
-    static const int cap = [] { const char* e = getenv("CELLSEG_EW_BLOCKS"); return e ? atoi(e) : 16384; }();        // A/B experiments only
+    static const int cap = cs_env_int_("CELLSEG_EW_BLOCKS", 16384);        // A/B experiments only
     long long b = (total + 255) / 256;
     if (b > cap) b = cap;
     if (b < 1) b = 1;

@@ -1044,9 +1044,9 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // Tile choice: wide-N tiles when there are enough output channels; shrink BM when the grid
 // would not fill the 256 CUs.  Returns BM*1000+BN.
 int igemm_tile(long long M, int NOUT) {
-    static const int forced = [] { const char* e = getenv("CELLSEG_TILE"); return e ? atoi(e) : 0; }();   // experiments only
+    static const int forced = cs_env_int_("CELLSEG_TILE", 0);   // experiments only
     if (forced) return (NOUT <= 64 && forced % 1000 == 128) ? forced - 64 : forced;
-    static const int thr = [] { const char* e = getenv("CELLSEG_TILE_THR"); return e ? atoi(e) : 1536; }();   // experiments only (A/B: 384..3072 within 1 %, 1536 best)
+    static const int thr = cs_env_int_("CELLSEG_TILE_THR", 1536);   // experiments only (A/B: 384..3072 within 1 %, 1536 best)
     const long long mt128 = (M + 127) / 128;
     if (NOUT > 64) {
         const long long blocks = mt128 * ((NOUT + 127) / 128);
@@ -1782,7 +1782,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned 
 // every slice costs one extra write + read of the whole dW in fp32, so no more than needed to fill the chip
 int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
     const int tiles = cs_ceil_div(KO, BM) * cs_ceil_div(QE, 128) * (n_items > 1 ? n_items : 1);
-    static const int target = [] { const char* e = getenv("CELLSEG_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();   // experiments only
+    static const int target = cs_env_int_("CELLSEG_WGRAD_BLOCKS", 512);   // experiments only
     long long want = (target + tiles - 1) / tiles;
     const long long max_split = (M + 63) / 64;
     if (want > max_split) want = max_split;
@@ -1792,7 +1792,7 @@ int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
     return (int)((M + per - 1) / per);
 }
 
-const int g_wgrad_nst = [] { const char* e = getenv("CELLSEG_WGRAD_NST"); return e ? atoi(e) : 3; }();   // A/B experiments only
+const int g_wgrad_nst = cs_env_int_("CELLSEG_WGRAD_NST", 3);   // A/B experiments only
 const bool g_wgrad_dma = [] { const char* e = getenv("CELLSEG_WGRAD_REG"); return !(e && atoi(e)); }();   // A/B experiments only
 
 template <typename T, int BM, int BN, bool TR>

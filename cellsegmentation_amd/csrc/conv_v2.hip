@@ -1095,7 +1095,7 @@ struct C2Plan {
 // workgroups: the same total work plus 241 more prologues, 31.9 -> 33.3 us) and layer4 (200 workgroups of 128 px, one per compute
 // unit; 64-px tiles re-read the 4.7 MB of weights twice as often and run into the L2 -> LDS feed, 33.4 -> 37.9 us).
 int pick_tm(long long M, int n_ntiles) {
-    static const int forced = [] { const char* e = getenv("CELLSEG_TM"); return e ? atoi(e) : 0; }();   // experiments only
+    static const int forced = cs_env_int_("CELLSEG_TM", 0);   // experiments only
     if (forced >= 2 && forced <= 4) return forced;
     const long long wg4 = ((M + 127) / 128) * n_ntiles, wg3 = ((M + 95) / 96) * n_ntiles;
     return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
@@ -1179,7 +1179,7 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     // (isolated, tools/conv_microbench.py shows the first-generation kernel ahead on >= 16 chunks -- 24.5 vs 29.1 us on 1024 -> 256 at
     // 19 x 19 -- but inside the training step the ring kernel wins on the family: 3.37 vs 3.43 ms per step; CELLSEG_RING_MAX_NCC
     // declines deeper contractions for A/B runs)
-    static const int max_ncc = [] { const char* e = getenv("CELLSEG_RING_MAX_NCC"); return e ? atoi(e) : 1 << 20; }();
+    static const int max_ncc = cs_env_int_("CELLSEG_RING_MAX_NCC", 1 << 20);
     if (ncc > max_ncc) return false;
     const long long M = (long long)g->N * DH * DW;
     const unsigned long long src_bytes = (unsigned long long)g->N * SH * SW * SC * 2ull;
@@ -1212,19 +1212,9 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     return true;
 }
 
-// dynamic LDS beyond 64 KiB has to be allowed per kernel, once (the table is keyed by the kernel's address; launches of one
-// process come from the threads that own a stream, a benign race re-raises the attribute)
+// dynamic LDS beyond 64 KiB has to be allowed per (device, kernel): cs_api.cpp keeps the table
 template <typename F> bool allow_lds(F fn, size_t bytes) {
-    if (bytes <= 65536) return true;
-    static const void* done[64];
-    static int n_done = 0;
-    for (int i = 0; i < n_done; ++i) if (done[i] == reinterpret_cast<const void*>(fn)) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) {
-        cs_set_error_("conv2: cannot raise the dynamic LDS limit");
-        return false;
-    }
-    if (n_done < 64) done[n_done++] = reinterpret_cast<const void*>(fn);
-    return true;
+    return cs_allow_dynamic_lds_(reinterpret_cast<const void*>(fn), bytes, 81920) != 0;
 }
 
 template <int TM, int WM, int WN, bool DG>

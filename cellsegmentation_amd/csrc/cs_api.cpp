@@ -1,5 +1,7 @@
 // ABI bookkeeping for libcellseg_hip.so: version + thread-local last-error string.
 #include <string.h>
+#include <mutex>
+#include <hip/hip_runtime_api.h>
 #include "../../include/cellseg_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -18,3 +20,23 @@ extern "C" void cs_set_variant_(const char* name) {
     g_variant[sizeof(g_variant) - 1] = '\0';
 }
 extern "C" const char* cs_last_conv_variant(void) { return g_variant; }
+
+// (device, kernel) pairs whose dynamic-LDS limit has been raised (the attribute is per device; the table is shared by
+// every launching thread)
+extern "C" void cs_set_error_(const char* msg);
+extern "C" int cs_allow_dynamic_lds_(const void* fn, size_t bytes, size_t limit) {
+    if (bytes <= 65536) return 1;
+    static std::mutex mu;
+    static struct { const void* fn; int dev; } done[512];
+    static int n_done = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { cs_set_error_("cannot query the current device"); return 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_done; ++i) if (done[i].fn == fn && done[i].dev == dev) return 1;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit) != hipSuccess) {
+        cs_set_error_("cannot raise the dynamic LDS limit of a kernel");
+        return 0;
+    }
+    if (n_done < 512) { done[n_done].fn = fn; done[n_done].dev = dev; ++n_done; }
+    return 1;
+}

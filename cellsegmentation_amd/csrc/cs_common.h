@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "../../include/cellseg_hip.h"
 
 typedef __bf16 bf16_t;
@@ -130,3 +131,17 @@ int cs_wgrad2_launch_(const CsConvGeom* g, int dtype, const void* const* x_tab, 
     } while (0)
 
 static inline int cs_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Dynamic LDS beyond 64 KiB has to be allowed per kernel AND per device (hipFuncSetAttribute applies to the device that is current
+// at the call).  cs_api.cpp keeps the (device, function) table under a mutex; `limit` is the byte count to allow (<= 160 KiB).
+extern "C" int cs_allow_dynamic_lds_(const void* fn, size_t bytes, size_t limit);
+
+// A/B knobs read from the environment: a positive integer, anything else (unset, 0, negative, non-numeric) -> `dflt`.
+static inline int cs_env_int_(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || v <= 0 || v > (1 << 24)) return dflt;
+    return (int)v;
+}

@@ -392,7 +392,7 @@ static int dw_stats_grid(const CsConvGeom* g) {
     while (b) { const int t = a % b; a = b; b = t; }           // gcd(CG, 256)
     const int m = CG / a;                                      // workgroup-count granule
     long long want = ((long long)g->N * g->P * g->Q * CG + 255) / 256;
-    static const int cap = [] { const char* e = getenv("CELLSEG_DW_STATS_BLOCKS"); return e ? atoi(e) : 1024; }();     // A/B experiments only
+    static const int cap = cs_env_int_("CELLSEG_DW_STATS_BLOCKS", 1024);     // A/B experiments only
     if (want > cap) want = cap;
     long long grid = (want + m - 1) / m * m;
     if (grid < m) grid = m;
@@ -442,7 +442,7 @@ extern "C" int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
 static void dw_wgrad_split(const CsConvGeom* g, int& rows_per_block, unsigned& nslab) {
     const long long rows = (long long)g->N * g->P;
     const int chunks = (g->C / 8 + 63) / 64 * ((g->R * g->R + kDwTaps - 1) / kDwTaps);
-    static const int dw_target = [] { const char* e = getenv("CELLSEG_DW_BLOCKS"); return e ? atoi(e) : 1024; }();   // A/B experiments only
+    static const int dw_target = cs_env_int_("CELLSEG_DW_BLOCKS", 1024);   // A/B experiments only
     long long slabs = dw_target / chunks;
     if (slabs < 1) slabs = 1;
     // every slab is one fp32 partial row of R*R*C floats for the fold: at most 32 MiB of them, at least 256

@@ -248,7 +248,7 @@ bool plan(const CsConvGeom* g, int dtype, int n_items, W2Plan& pl) {
     // split the positions until ~CELLSEG_WGRAD2_BLOCKS workgroups exist; every split costs one write + read of |dW| in fp32 and
     // a split should hold at least 4 stages (its first loads and its 144 stores per wave are not overlapped with anything)
     // (measured, bench.py: 256 / 384 / 512 / 768 / 1024 workgroups -> 0.643 / 0.572 / 0.596 / 0.575 / 0.578 ms per step for the family)
-    static const int target = [] { const char* e = getenv("CELLSEG_WGRAD2_BLOCKS"); return e ? atoi(e) : 384; }();
+    static const int target = cs_env_int_("CELLSEG_WGRAD2_BLOCKS", 384);
     const long long tiles = (long long)p.n_kt * p.n_ct * n_items;
     long long want = (target + tiles - 1) / tiles;
     const long long max_split = p.n_stages / 4 > 0 ? p.n_stages / 4 : 1;
@@ -266,14 +266,7 @@ bool plan(const CsConvGeom* g, int dtype, int n_items, W2Plan& pl) {
 template <int BL, int XR>
 int launch_t(const W2Params& p, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)(BL + XR) * 128;
-    static bool raised = false;
-    if (lds > 65536 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_kernel<BL, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) {
-            cs_set_error_("wgrad2: cannot raise the dynamic LDS limit");
-            return CS_ERR_LAUNCH;
-        }
-        raised = true;
-    }
+    if (!cs_allow_dynamic_lds_(reinterpret_cast<const void*>(wgrad2_kernel<BL, XR>), lds, 81920)) return CS_ERR_LAUNCH;
     char name[48];
     snprintf(name, sizeof(name), "wgrad2_kernel<%d,%d>", BL, XR);
     cs_set_variant_(name);

@@ -176,7 +176,7 @@ def _bn_uses_batch_stats(bn, bn_train):
     return bn is not None and bn_train and bn.training
 
 
-def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits):
+def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits, bn_train=False):
     """(forward operand packed?, data-gradient operand packed?) for the packed-operand kernels of csrc/conv_v2.hip.
     The data gradient only qualifies when its ReLU mask (if it applies one) exists as a bit tensor."""
     if not PACKED or batch_stats or u.grouped or u.act not in (ACT_NONE, ACT_RELU):
@@ -186,12 +186,14 @@ def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits):
     if pkb and geom.stride != 1:
         # a strided 1x1 data gradient is served in COMPACT form (kernels.CompactGrad): only where the other consumer of the block
         # input is the stride-1 1x1 convolution whose packed data gradient runs AFTER this one in backward order and adds it
-        pkb = _compact_partner(plan, u, geom, dtype, bits) is not None
+        pkb = _compact_partner(plan, u, geom, dtype, bits, bn_train) is not None
     return pkf, pkb
 
 
-def _compact_partner(plan, u, geom, dtype, bits):
-    """The unit whose data gradient will take u's compact gradient as its strided add operand, or None."""
+def _compact_partner(plan, u, geom, dtype, bits, bn_train=False):
+    """The unit whose data gradient will take u's compact gradient as its strided add operand, or None.  The partner must itself
+    be staged bwd_packed in this pass: same eligibility as _packed_flags applies to it, including ITS BatchNorm mode (a model
+    with mixed frozen / train-mode BN layers falls back to the dense strided gradient instead of raising in backward)."""
     others = [(i, v) for i, v in enumerate(plan.units) if v is not u and v.kind == "conv" and v.src == u.src]
     if len(others) != 1 or plan.consumers.get(u.src, 0) != 2:
         return None
@@ -199,6 +201,8 @@ def _compact_partner(plan, u, geom, dtype, bits):
     iu = plan.units.index(u)
     c = v.conv
     if iv > iu or v.grouped or v.act not in (ACT_NONE, ACT_RELU) or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0):
+        return None
+    if not PACKED or _bn_uses_batch_stats(v.bn, bn_train):
         return None
     if u.src in plan.relu_slots and u.src not in bits:
         return None
@@ -325,7 +329,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
             need_bwd = save and requires.get(u.src, False)
             batch_stats = _bn_uses_batch_stats(u.bn, bn_train)
             pre = prestaged.get(ui)
-            pkf, pkb = _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits)
+            pkf, pkb = _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits, bn_train)
             # A pass that will be followed by an optimizer step, or that updates BN running statistics in place, must not leave
             # a version-keyed cache behind: fused optimizers and our own kernels write those tensors without bumping `_version`
             # (a later no-grad pass would be served the old weights; the one-launch pack path below never touches `_cache`)

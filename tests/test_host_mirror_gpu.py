@@ -297,3 +297,36 @@ def test_training_reduces_the_loss_bf16(dev):
         m.eval()
         acc = float((m(x).argmax(1) == y).float().mean())
     assert acc >= 0.9, acc
+
+
+def test_mixed_frozen_and_train_mode_batchnorm_trains(dev):
+    """a strided shortcut whose own BN is frozen (folded, packed, compact gradient) next to a conv1 whose BN uses batch
+    statistics (not packed) must fall back to the dense strided data gradient instead of raising 'a compact gradient reached a
+    data gradient that cannot add it'.  Gradients equal the all-first-generation path (CELLSEG_PACKED=0 semantics)."""
+    from cellsegmentation_amd import engine as E
+    torch.manual_seed(0)
+
+    def run(packed):
+        old = E.PACKED
+        E.PACKED = packed
+        try:
+            m = _model("resnet50", dev).set_compute_dtype(torch.bfloat16)
+            m.setmode("image")
+            m.train()
+            for blk in (m.layer2[0], m.layer3[0], m.layer4[0]):
+                blk.downsample[1].eval()                     # frozen statistics on the shortcut only
+            x = synth.normalise(synth.ihc_tiles(4, 96, 77)).to(dev)
+            cls, reg = m(x)
+            (cls.float().square().mean() + reg.float().square().mean()).backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            E.PACKED = old
+
+    got, ref = run(True), run(False)
+    assert set(got) == set(ref) and "layer2.0.conv1.weight" in got
+    for k in ("conv1.weight", "layer1.0.conv1.weight", "layer2.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.0.conv1.weight"):
+        a, b = got[k], ref[k]
+        assert torch.isfinite(a).all()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.98, (k, cos)
