@@ -227,16 +227,17 @@ def _host_cpu():
     return model, max(1, min(physical, max(1, avail // threads_per_core) if avail < physical * threads_per_core else physical))
 
 
-def cpu_baseline(micro=16, accum=4, steps=3):
+def cpu_baseline(micro=16, accum=4, steps=2):
     """The oracle (torch CPU fp32 NCHW, proven equal to the reference in tests/golden/make_golden.py) on the same step definition
     and the same bag of 64 tiles as the GPU (N = 64 as 16 x 4 -- four micro-batches accumulate into one
-    optimizer step; with BatchNorm frozen the gradients are identical to one batch of 64), 1 warm-up micro-batch + `steps` timed
-    steps, all physical cores of the box this process may use."""
+    optimizer step; with BatchNorm frozen the gradients are identical to one batch of 64).
+
+    oneDNN's fp32 backward at micro-batch 16 does not scale to every core of a 128-core host (round 2: 2.8 tiles/s on 128 threads,
+    10-15 on 16), so the number of record is the BEST of a thread sweep {16, 32, 64, all physical cores}: per candidate one warm-up
+    and one timed micro-batch (16 tiles fwd+bwd), then `steps` full steps (4 micro-batches + Adam) at the fastest setting.  The
+    sweep and the thread count used are part of the JSON."""
     from oracle import cellseg_oracle as orc
     model_name, cores = _host_cpu()
-    if os.environ.get("CELLSEG_CPU_THREADS"):
-        cores = max(1, int(os.environ["CELLSEG_CPU_THREADS"]))
-    torch.set_num_threads(cores)
     n = micro * accum
     base = synth.normalise(synth.ihc_tiles(8, SIZE, 1234))
     x = base.repeat(n // 8, 1, 1, 1).contiguous()
@@ -249,19 +250,39 @@ def cpu_baseline(micro=16, accum=4, steps=3):
             v.requires_grad_()
             params.append(v)
     opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4)
-    (orc.tile_step_loss(sd, x[:micro], labels[:micro], ARCH)).backward()        # warm-up (allocator, oneDNN primitives)
+
+    def micro_step(a, scale=1.0):
+        sl = slice(a * micro, (a + 1) * micro)
+        (orc.tile_step_loss(sd, x[sl], labels[sl], ARCH) * scale).backward()
+
+    if os.environ.get("CELLSEG_CPU_THREADS"):
+        cands = [max(1, int(os.environ["CELLSEG_CPU_THREADS"]))]
+    else:
+        cands = sorted({t for t in (16, 32, 64, cores) if t <= cores} or {cores})
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        opt.zero_grad()
+        micro_step(0)                                   # warm-up at this thread count (allocator, oneDNN primitives)
+        t0 = time.perf_counter()
+        micro_step(1)
+        sweep[t] = round(micro / (time.perf_counter() - t0), 3)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     times = []
     for it in range(steps):
         t0 = time.perf_counter()
         opt.zero_grad()
         for a in range(accum):
-            sl = slice(a * micro, (a + 1) * micro)
-            (orc.tile_step_loss(sd, x[sl], labels[sl], ARCH) * (micro / n)).backward()
+            micro_step(a, micro / n)
         opt.step()
         times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
-    return {"value": round(n / t, 3), "unit": "tiles/s", "cores": cores, "kind": "port", "cpu_model": model_name,
-            "sample": f"bag of {n} tiles as {accum} x {micro}, {steps} timed steps (1 warm-up micro-batch), ResNet-50 tile fwd+bwd+Adam fp32, median",
+    t = sorted(times)[len(times) // 2] if len(times) % 2 else min(times)
+    return {"value": round(n / t, 3), "unit": "tiles/s", "cores": best, "threads": best, "physical_cores": cores, "kind": "port",
+            "cpu_model": model_name,
+            "thread_sweep_tiles_per_s": {str(k): v for k, v in sweep.items()},
+            "sample": f"thread sweep {cands} on one micro-batch of {micro} tiles (fwd+bwd) each, then {steps} full steps at the best "
+                      f"({best} threads): bag of {n} tiles as {accum} x {micro} + Adam, ResNet-50 tile fp32",
             "s_per_step": round(t, 3)}
 
 
@@ -296,6 +317,32 @@ def cpu_baseline_c1(steps=5):
             "sample": f"ResNet-18 image counter B=8 fp32, median of {steps} steps", "s_per_step": round(t, 4)}
 
 
+def fp32_parity_mode_rate(dev, x, labels, steps=5, warmup=2):
+    """The same step in fp32 PARITY mode (exact-f32 MFMA, fp32 activations: the mode in which tests/test_model_parity_gpu.py proves
+    the 1e-4 agreement with the reference's vectors), outside the timed region: SURVEY section 7 hard part (ii) asks for both numbers
+    side by side.  Never `value`."""
+    model = build_model(dev, torch.float32)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4, fused=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = HF.cross_entropy(model(x, freeze_bn=True), labels, 1.0)
+        loss.backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(BAG / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": "fp32",
+            "note": "fp32 activations + v_mfma_f32_32x32x2_f32 (first-generation kernels); the mode of the 1e-4 parity tests"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +350,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32 parity-mode side number (N=1, bf16 runs)")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
     ap.add_argument("--event-every", type=int, default=5, help="HIP-event-bracket the conv launches of every Nth timed step (1 = all)")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-geometry launch table to stderr")
@@ -401,6 +449,9 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+        fp32_side = None
+        if world == 1 and args.dtype == "bf16" and not args.no_fp32_side:
+            fp32_side = fp32_parity_mode_rate(dev, x, labels)
         out = {
             "metric": "tiles/sec fwd+bwd (ResNet-50 MIL, 299x299)",
             "value": round(world * BAG * args.steps / elapsed, 2),
@@ -419,6 +470,7 @@ def main():
                        "parallelism": f"dp{world}", "mean_loss": round(final_loss, 5)},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "fp32_parity_mode": fp32_side,
         }
         print(json.dumps(out))
     if world > 1:
