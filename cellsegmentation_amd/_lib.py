@@ -59,6 +59,7 @@ _SIGNATURES = {
     "cs_conv2d_wgrad_splits": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_weight_prep_grouped": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "cs_conv2d_wgrad_batched_splits": (c_int, [POINTER(CsConvGeom), c_int, c_int]),
+    "cs_conv2d_wgrad2_supported": (c_int, [POINTER(CsConvGeom), c_int]),
     "cs_conv2d_wgrad_batched": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, c_int, c_int, _P]),
     "cs_wgrad_finalize_batched": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_conv2d_dgrad_partial_rows": (c_int, [POINTER(CsConvGeom)]),
@@ -67,6 +68,7 @@ _SIGNATURES = {
     "cs_colsum": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_colsum_partial_rows": (c_int, [c_longlong]),
     "cs_colsum_partial": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
+    "cs_positive_bits": (c_int, [_P, c_int, c_longlong, _P, _P]),
     "cs_maxpool3x3s2_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_gap_avgmax_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -101,39 +101,64 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long M
     }
 }
 
+// Row-strided element-wise passes (round 3): a thread keeps ONE 8-channel group and walks rows r0 + rr, r0 + rr + rpar, ... of its
+// workgroup's row block, so every per-channel constant is loaded and combined once per thread -- round 2's flat index walk re-read
+// 4-6 parameter vectors (and, in the backward apply, 16 fp64 sums) per 16 bytes of data: instruction-bound at 1.8-2.3 TB/s on the
+// EfficientNet-B3 step.  Two rows (4-6 independent 16-byte loads) are in flight per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual,
-                                                       int act, T* __restrict__ y, long long M, int C) {
+                                                       int act, T* __restrict__ y, long long M, int C, int rows_per_block) {
     const int CG = C / 8;
-    const long long total = M * CG;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int cg = (int)(idx % CG);
-        const long long off = (idx / CG) * C + cg * 8;
-        float v[8], mu[8], rs[8], gm[8], bt[8];
-        load8<T>(z + off, v);
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+        const int rpar = 256 / width;
+        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int rr = threadIdx.x / width;
+        if (rr >= rpar) continue;
+        float mu[8], rs[8], gm[8], bt[8];
         load8p(mean + cg * 8, 0.f, mu);
         load8p(rstd + cg * 8, 1.f, rs);
         load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
         load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
+        auto finish = [&](float (&v)[8], const long long off) {
+            // (z - mean) * rstd * gamma + beta in the reference's operation order
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu[e]) * rs[e] * gm[e] + bt[e];
-        if (residual) {
-            float r8[8];
-            load8<T>(residual + off, r8);
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu[e]) * rs[e] * gm[e] + bt[e];
+            if (residual) {
+                float r8[8];
+                load8<T>(residual + off, r8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                for (int e = 0; e < 8; ++e) v[e] += r8[e];
+            }
+            if (act == CS_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (act == CS_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+            }
+            store8<T>(y + off, v);
+        };
+        long long r = r0 + rr;
+        for (; r + rpar < r1; r += 2LL * rpar) {
+            const long long o0 = r * C + cg * 8, o1 = (r + rpar) * C + cg * 8;
+            float v0[8], v1[8];
+            load8<T>(z + o0, v0);
+            load8<T>(z + o1, v1);
+            finish(v0, o0);
+            finish(v1, o1);
         }
-        if (act == CS_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        } else if (act == CS_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+        if (r < r1) {
+            const long long o0 = r * C + cg * 8;
+            float v0[8];
+            load8<T>(z + o0, v0);
+            finish(v0, o0);
         }
-        store8<T>(y + off, v);
     }
 }
 
@@ -171,16 +196,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             load8p(rstd + cg * 8, 1.f, rs);
             load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
             load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
-            for (long long r = r0 + rr; r < r1; r += rpar) {
-                float g[8], zz[8];
-                load8<T>(dy + r * C + cg * 8, g);
-                load8<T>(z + r * C + cg * 8, zz);
+            auto acc = [&](const float (&g)[8], const float (&zz)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xh = (zz[e] - mu[e]) * rs[e];
                     const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
                     s0[e] += gu; s1[e] += gu * xh;
                 }
+            };
+            long long r = r0 + rr;
+            for (; r + rpar < r1; r += 2LL * rpar) {             // four independent 16-byte loads in flight per thread
+                float g0[8], z0[8], g1[8], z1[8];
+                load8<T>(dy + r * C + cg * 8, g0);
+                load8<T>(z + r * C + cg * 8, z0);
+                load8<T>(dy + (r + rpar) * C + cg * 8, g1);
+                load8<T>(z + (r + rpar) * C + cg * 8, z1);
+                acc(g0, z0);
+                acc(g1, z1);
+            }
+            if (r < r1) {
+                float g0[8], z0[8];
+                load8<T>(dy + r * C + cg * 8, g0);
+                load8<T>(z + r * C + cg * 8, z0);
+                acc(g0, z0);
             }
         }
         block_fold_atomic(s0, s1, width, rpar, cg, live, sums, sums + C, partial, C);
@@ -192,9 +230,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                            const double* __restrict__ sums,
-                                                           long long M, int C, T* __restrict__ dz, float* dgamma, float* dbeta) {
+                                                           long long M, int C, T* __restrict__ dz, float* dgamma, float* dbeta,
+                                                           int rows_per_block) {
     const int CG = C / 8;
-    const long long total = M * CG;
     const float invM = 1.f / (float)M;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -202,25 +240,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (dgamma) dgamma[c] = (float)sums[C + c];
         }
     }
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int cg = (int)(idx % CG);
-        const long long off = (idx / CG) * C + cg * 8;
-        float g[8], zz[8], o[8], mu[8], rs[8], gm[8], bt[8];
-        load8<T>(dy + off, g);
-        load8<T>(z + off, zz);
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+        const int rpar = 256 / width;
+        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int rr = threadIdx.x / width;
+        if (rr >= rpar) continue;
+        float mu[8], rs[8], gm[8], bt[8], k0[8], k1[8], gr[8];
         load8p(mean + cg * 8, 0.f, mu);
         load8p(rstd + cg * 8, 1.f, rs);
         load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
         load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            const float xh = (zz[e] - mu[e]) * rs[e];
-            const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
-            o[e] = gm[e] * rs[e] * (gu - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
+            k0[e] = (float)sums[cg * 8 + e] * invM;
+            k1[e] = (float)sums[C + cg * 8 + e] * invM;
+            gr[e] = gm[e] * rs[e];
         }
-        store8<T>(dz + off, o);
+        auto finish = [&](const float (&g)[8], const float (&zz)[8], const long long off) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (zz[e] - mu[e]) * rs[e];
+                const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
+                o[e] = gr[e] * (gu - k0[e] - xh * k1[e]);
+            }
+            store8<T>(dz + off, o);
+        };
+        long long r = r0 + rr;
+        for (; r + rpar < r1; r += 2LL * rpar) {
+            const long long o0 = r * C + cg * 8, o1 = (r + rpar) * C + cg * 8;
+            float g0[8], z0[8], g1[8], z1[8];
+            load8<T>(dy + o0, g0);
+            load8<T>(z + o0, z0);
+            load8<T>(dy + o1, g1);
+            load8<T>(z + o1, z1);
+            finish(g0, z0, o0);
+            finish(g1, z1, o1);
+        }
+        if (r < r1) {
+            const long long o0 = r * C + cg * 8;
+            float g0[8], z0[8];
+            load8<T>(dy + o0, g0);
+            load8<T>(z + o0, z0);
+            finish(g0, z0, o0);
+        }
     }
 }
 
@@ -260,12 +327,12 @@ inline int rows_per_block_for(long long M) {
     return (int)r;
 }
 
-inline int grid_ew(long long total) {
-    static const int cap = cs_env_int_("CELLSEG_EW_BLOCKS", 16384);        // A/B experiments only
-    long long b = (total + 255) / 256;
-    if (b > cap) b = cap;
-    if (b < 1) b = 1;
-    return (int)b;
+// row block of the element-wise passes: ~CELLSEG_EW_BLOCKS (2048: 8 workgroups per compute unit) blocks, at least 16 rows each
+inline int ew_rows_per_block(long long M) {
+    static const int target = cs_env_int_("CELLSEG_EW_BLOCKS", 2048);       // A/B experiments only
+    long long r = (M + target - 1) / target;
+    if (r < 16) r = 16;
+    return (int)r;
 }
 
 }  // namespace
@@ -319,12 +386,13 @@ extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const fl
                            const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream) {
     CS_CHECK_ARG(z && y && mean && rstd && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int grid = grid_ew(M * (C / 8));
+    const int rpb = ew_rows_per_block(M);
+    const int grid = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, mean, rstd, gamma, beta,
-                                     (const float*)residual, act, (float*)y, M, C),
+                                     (const float*)residual, act, (float*)y, M, C, rpb),
                   hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)z, mean, rstd, gamma, beta,
-                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C),
+                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, rpb),
                   "bn_apply");
     CS_LAUNCH_CHECK();
     return CS_OK;
@@ -356,12 +424,13 @@ extern "C" int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const f
                                float* dgamma, float* dbeta, void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && dz && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int grid = grid_ew(M * (C / 8));
+    const int rpb = ew_rows_per_block(M);
+    const int grid = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
-                                     rstd, gamma, beta, act, sums, M, C, (float*)dz, dgamma, dbeta),
+                                     rstd, gamma, beta, act, sums, M, C, (float*)dz, dgamma, dbeta, rpb),
                   hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, mean,
-                                     rstd, gamma, beta, act, sums, M, C, (bf16_t*)dz, dgamma, dbeta),
+                                     rstd, gamma, beta, act, sums, M, C, (bf16_t*)dz, dgamma, dbeta, rpb),
                   "bn_bwd_apply");
     CS_LAUNCH_CHECK();
     return CS_OK;

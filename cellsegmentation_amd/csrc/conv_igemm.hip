@@ -1854,6 +1854,8 @@ extern "C" int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int dtype, in
     return wgrad_splits((long long)g->N * g->P * g->Q, g->K, g->R * g->S * g->C, g->K > 64 ? 128 : 64, n_items);
 }
 
+extern "C" int cs_conv2d_wgrad2_supported(const CsConvGeom* g, int dtype) { return g && cs_wgrad2_splits_(g, dtype, 1) > 0 ? 1 : 0; }
+
 extern "C" int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
                                        float* const* dw_tab, int n_items, int use_tr_read, void* stream) {
     int rc = check_geom(g, dtype);

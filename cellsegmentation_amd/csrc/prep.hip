@@ -643,6 +643,43 @@ static int colsum_rows_per_block(long long M) {
     return (int)(rows < 64 ? 64 : rows);
 }
 
+// bits[i >> 3] bit (i & 7) = (x[i] > 0) for a bf16 tensor with a multiple of 32 elements: the ReLU-mask bit plane of conv_v2's
+// data-gradient epilogue (one byte per pixel per 8 channels) for tensors no convolution epilogue produced (a train-mode BN + ReLU
+// output, a concatenation of two such tensors).  One lane = 32 elements in, one dword out.
+__global__ __launch_bounds__(256) void positive_bits_kernel(const uint4* __restrict__ x, unsigned* __restrict__ bits, long long n32) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n32; i += (long long)gridDim.x * 256) {
+        unsigned out = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = x[i * 4 + q];
+            const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+            unsigned b = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = wds[e] & 0xffffu, hi = wds[e] >> 16;
+                // > 0: sign clear and magnitude non-zero (NaN patterns count as positive exactly like `x > 0` does not -- a NaN
+                // never reaches here: the tensors are ReLU outputs)
+                b |= ((lo != 0u && !(lo & 0x8000u)) ? 1u : 0u) << (2 * e);
+                b |= ((hi != 0u && !(hi & 0x8000u)) ? 1u : 0u) << (2 * e + 1);
+            }
+            out |= b << (8 * q);
+        }
+        bits[i] = out;
+    }
+}
+
+extern "C" int cs_positive_bits(const void* x, int dtype, long long n_elems, uint8_t* bits, void* stream) {
+    CS_CHECK_ARG(x && bits && n_elems > 0 && n_elems % 32 == 0, "positive_bits: need a positive multiple of 32 elements");
+    CS_CHECK_ARG(dtype == CS_BF16, "positive_bits: bf16 tensors only (the bit planes belong to the packed bf16 kernels)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long long n32 = n_elems / 32;
+    long long blocks = (n32 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(positive_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)x, (unsigned*)bits, n32);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
 extern "C" int cs_colsum_partial_rows(long long M) {
     if (M <= 0) return 0;
     const int rows = colsum_rows_per_block(M);

@@ -179,8 +179,18 @@ def _bn_uses_batch_stats(bn, bn_train):
 def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits, bn_train=False):
     """(forward operand packed?, data-gradient operand packed?) for the packed-operand kernels of csrc/conv_v2.hip.
     The data gradient only qualifies when its ReLU mask (if it applies one) exists as a bit tensor."""
-    if not PACKED or batch_stats or u.grouped or u.act not in (ACT_NONE, ACT_RELU):
+    if not PACKED or u.grouped or u.act not in (ACT_NONE, ACT_RELU):
         return False, False
+    if batch_stats:
+        # Batch-statistics BN: the packed kernels have no statistics epilogue (16 more live registers spill under their cap), so
+        # z is written first and one cs_bn_stats pass reads it back.  Only where that pass is noise next to the MFMA work: dense
+        # stride-1 3x3 convolutions of >= 128 channels (the segmentation decoder, resnet.py:195-200 -- 86 % of segment-mode FLOPs).
+        # Their ReLU masks, where no bit plane exists, are made on demand in backward (kernels.positive_bits).
+        if not (PACKED_TRAIN_BN and geom.R == 3 and geom.S == 3 and geom.stride == 1 and min(geom.C, geom.K) >= 128):
+            return False, False
+        pkf = K.packed_supported(geom, dtype, dgrad=False)
+        pkb = bool(need_bwd) and K.packed_supported(geom, dtype, dgrad=True) and geom.C % 32 == 0
+        return pkf, pkb
     pkf = K.packed_supported(geom, dtype, dgrad=False)
     pkb = bool(need_bwd) and K.packed_supported(geom, dtype, dgrad=True) and (u.src not in plan.relu_slots or u.src in bits)
     if pkb and geom.stride != 1:
@@ -371,6 +381,10 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 stats = take_stats(Kp)
                 if stem:
                     z = K.stem_fwd(geom, xp, wp, None, st.shift, ACT_NONE, stats=stats)
+                elif getattr(st, "fwd_packed", False):
+                    # halo kernel + one statistics pass over the stored z (the statistics of exactly the values bn_apply normalises)
+                    z = K.conv_fwd_packed(geom, x, st.w_khwc, st.shift, None, ACT_NONE)
+                    K.bn_stats(z, stats)
                 else:
                     z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats, grouped=u.grouped)
                 M = N * geom.P * geom.Q
@@ -472,6 +486,7 @@ def _defers(u, a, need, ui):
             and not a.train and not u.grouped and u.bn is not None and u.conv.bias is None)
 
 
+PACKED_TRAIN_BN = os.environ.get("CELLSEG_PACKED_TRAIN_BN", "1") != "0"   # ... also for heavy 3x3 convolutions under batch-statistics BN
 PACKED = os.environ.get("CELLSEG_PACKED", "1") != "0"                # packed-operand conv kernels (0: first-generation igemm everywhere)
 RELU_BITS = os.environ.get("CELLSEG_RELU_BITS", "1") != "0"          # bit masks next to ReLU outputs (0: bf16 tensors as masks)
 STEM_PAIRED = os.environ.get("CELLSEG_STEM_PAIRED", "1") != "0"      # pixel-paired stem (0: the generic 7x7 path, for A/B runs)
@@ -663,6 +678,8 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum_cache[u.res] = gsum      # the residual branch receives the very same gradient tensor
                 if a.xp is not None:
                     raw = K.stem_wgrad(geom, a.xp, dz, use_tr_read=use_tr_read)
+                elif not u.grouped and K.wgrad2_serves(geom, x.dtype):
+                    raw = K.wgrad_batched(geom, [x], [dz], use_tr_read=use_tr_read)[0]      # wgrad_v2.hip (the batched entry routes to it)
                 else:
                     raw = K.new_wgrad_buffer(geom, x.device, u.grouped)
                     K.conv_wgrad(geom, x, dz, raw, use_tr_read=use_tr_read, grouped=u.grouped)
@@ -703,6 +720,8 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         raise RuntimeError(f"{u.name}: compact strided data gradient out of order (it must be the first contribution)")
                     dx = K.conv_dgrad_packed(geom, dz, a.st.w_chwk)          # kernels.CompactGrad: consumed as a strided add operand
                 elif getattr(a.st, "bwd_packed", False):
+                    if mask is not None and a.train:
+                        mbits, mask = K.positive_bits(mask), None          # (a train-mode BN + ReLU output / a concatenation of such)
                     if mask is not None:
                         raise RuntimeError(f"{u.name}: packed data-gradient operand staged but the ReLU mask is not a bit tensor")
                     if final:

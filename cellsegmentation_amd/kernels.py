@@ -470,6 +470,11 @@ def conv_wgrad(geom, x, dy, dw_raw, use_tr_read=True, grouped=False):
     return dw_raw
 
 
+def wgrad2_serves(geom, dtype):
+    """True when the batched weight-gradient entry runs this geometry on the second-generation kernel (csrc/wgrad_v2.hip)."""
+    return bool(_lib.load().cs_conv2d_wgrad2_supported(ctypes.byref(geom), _code(dtype)))
+
+
 def wgrad_batched(geom, xs, dys, use_tr_read=True):
     """Batched wgrad over len(xs) <= 8 layers of identical geometry.  Returns the split-K slab buffer [n, nsplit, K, R, S, Cp]."""
     n = len(xs)
@@ -533,6 +538,17 @@ def colsum(g, out=None):
         return colsum_partial(g).vector()
     _lib.check(_lib.load().cs_colsum(_p(g), _code(g.dtype), M, C, _p(out), _stream()), "colsum")
     return out
+
+
+def positive_bits(x):
+    """uint8 [..., C/8] bit plane of a bf16 NHWC tensor: bit (c & 7) of byte c >> 3 = x[..., c] > 0 -- the `mask_bits` operand of the packed
+    data gradients for a post-ReLU tensor that no convolution epilogue produced (train-mode BN + ReLU outputs, their concatenation)."""
+    C = x.shape[-1]
+    if x.dtype != torch.bfloat16 or C % 32 or not x.is_contiguous():
+        raise ValueError("positive_bits: contiguous bf16 tensor with a channel count that is a multiple of 32")
+    bits = torch.empty(x.shape[:-1] + (C // 8,), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().cs_positive_bits(_p(x), _code(x.dtype), x.numel(), _p(bits), _stream()), "positive_bits")
+    return bits
 
 
 def colsum_partial(g):

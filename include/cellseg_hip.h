@@ -167,6 +167,9 @@ int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* d
  * proportionally less partial-slab traffic).  x_tab / dy_tab / dw_tab: HOST arrays of n_items (<= 8) device pointers (they
  * are passed to the kernel by value, no device table, no copy); dw_tab[i] is a [nsplit][K][R][S][Cp] fp32 buffer. */
 int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int dtype, int n_items);
+/* 1 when cs_conv2d_wgrad_batched serves this geometry with the second-generation kernel (wgrad_v2.hip: bf16, stride-1 pad-1 3x3,
+ * C and K multiples of 64, image width <= 78): callers with a single layer then prefer the batched entry (n_items = 1). */
+int cs_conv2d_wgrad2_supported(const CsConvGeom* g, int dtype);
 int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
                             float* const* dw_tab, int n_items, int use_tr_read, void* stream);
 /* Batched cs_wgrad_finalize (eval-BN or plain conv, no bias, not grouped) in ONE launch: `tables` = HOST array of 9*n_items
@@ -200,6 +203,9 @@ int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* st
 /* The same sums left as per-workgroup partial rows (layout and consumers as for cs_conv2d_dgrad's deferred column sums):
  * partial[b * 2*C + c], b < cs_colsum_partial_rows(M); no atomics, no zero-fill. */
 int cs_colsum_partial_rows(long long M);
+/* bit plane of a bf16 NHWC tensor: bits[i >> 3] bit (i & 7) = x[i] > 0 (the `mask_bits` operand of cs_conv2d_dgrad_packed for a
+ * post-ReLU tensor that no convolution epilogue produced, e.g. torch.cat of two ReLU outputs, resnet.py:284-294); n_elems % 32 == 0 */
+int cs_positive_bits(const void* x, int dtype, long long n_elems, uint8_t* bits, void* stream);
 int cs_colsum_partial(const void* g, int dtype, long long M, int C, float* partial, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------

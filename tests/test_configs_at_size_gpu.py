@@ -249,3 +249,48 @@ def test_stochastic_depth_row_mode_statistics(dev):
     with torch.no_grad():
         e1, e2 = m(xs).clone(), m(xs).clone()
     assert torch.equal(e1, e2)
+
+
+def test_decoder_convs_on_the_packed_kernels_match_the_first_generation_path(dev):
+    """Round 3: the heavy 3x3 convolutions of the segmentation decoder (bias + batch-statistics BN + ReLU, resnet.py:195-200) run on
+    the halo / wgrad2 kernels with a separate statistics pass and on-demand ReLU bit planes.  Yardstick = the same step in fp32
+    parity mode; the packed bf16 route must be as close to it as the first-generation bf16 route is (both are bf16 noise through
+    8 train-mode BN layers at n = 2), tensor by tensor."""
+
+    def run(flag, dtype):
+        old = E.PACKED_TRAIN_BN
+        E.PACKED_TRAIN_BN = flag
+        try:
+            torch.manual_seed(0)
+            m = R.MILresnet50()
+            sd = m.state_dict()
+            synth.fill_state_dict(sd)
+            m.load_state_dict(sd)
+            m = m.to(dev).set_compute_dtype(dtype)
+            m.setmode("segment")
+            m.train()
+            x = synth.normalise(synth.ihc_tiles(2, 299, 31)).to(dev)
+            mask = (torch.rand(2, 299, 299, generator=torch.Generator().manual_seed(5)) > 0.8).float().to(dev)
+            loss = HF.dice_loss(HF.softmax_channel(m(x), 1), mask)
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            E.PACKED_TRAIN_BN = old
+
+    def cos(a, b):
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+
+    lt, gt = run(False, torch.float32)
+    l1, g1 = run(True, torch.bfloat16)
+    l0, g0 = run(False, torch.bfloat16)
+    assert abs(l1 - lt) < 2e-2 * abs(lt) + 1e-3, (l1, lt)
+    assert set(g1) == set(g0) == set(gt)
+    worst = []
+    for k in ("upconv1.0.weight", "upconv2.0.weight", "upconv3.0.weight", "upconv4.0.weight", "upconv5.0.weight", "upconv6.0.weight",
+              "upconv7.0.weight", "upconv8.0.weight", "upconv2.1.weight", "upconv4.1.bias", "seg_out_conv.weight"):
+        assert torch.isfinite(g1[k]).all(), k
+        c1, c0 = cos(g1[k], gt[k]), cos(g0[k], gt[k])
+        if c1 < 0.93 or c1 < c0 - 0.03:
+            worst.append((k, round(c1, 4), round(c0, 4)))
+    assert not worst, worst

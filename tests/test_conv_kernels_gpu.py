@@ -232,3 +232,47 @@ def test_paired_stem_equals_the_generic_7x7_path(dev, dtype, hw):
     scale = float(ref.abs().max())
     assert float((raw[0] - ref).abs().max()) <= (1e-4 if dtype == torch.float32 else 1e-3) * scale
     assert float(raw[0][..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("K_,Cin,R,Cp,nsplit,n", [
+    (64, 64, 1, 64, 512, 1),        # layer1 64->64 1x1: one tile, split ~500 ways (16 float4 items per row, 16 split lanes)
+    (256, 64, 1, 64, 64, 4),        # layer1 64->256 x4
+    (64, 64, 3, 64, 126, 3),        # layer1 3x3 x3: 1024-thread workgroups, 144 items
+    (64, 3, 7, 8, 37, 1),           # stem: Cin 3 padded to 8, 49 taps
+    (512, 2048, 1, 2048, 4, 2),     # layer4 2048->512: 512 items per row
+    (256, 256, 3, 256, 5, 5),       # layer3 3x3 x5: 256-thread workgroups, two channel tiles
+    (40, 24, 3, 24, 9, 2),          # odd sizes (Cin not a multiple of 4 is not served by the packed path, 24 is)
+    (24, 6, 1, 8, 3, 1),            # Cin % 4 != 0: scalar tail of the 1x1 path
+])
+def test_wgrad_finalize_batched_matches_torch(K_, Cin, R, Cp, nsplit, n, dev):
+    """cs_wgrad_finalize_batched (one launch per group of identical layers): dw[k][c][r][s] = scale[k] * sum over the split-K slabs,
+    dgamma = rstd * (<w, raw> - mean * gsum), dbeta = gsum, for every access shape of the float4 / split-lane rewrite of round 3."""
+    torch.manual_seed(K_ + Cin + R)
+    slabs = torch.randn(n, nsplit, K_, R, R, Cp)
+    slabs[..., Cin:] = 7.0                                   # padding channels hold garbage: must never reach dw
+    ws = [torch.randn(K_, Cin, R, R) for _ in range(n)]
+    scales = [torch.rand(K_) + 0.5 for _ in range(n)]
+    rstds = [torch.rand(K_) + 0.5 for _ in range(n)]
+    means = [torch.randn(K_) for _ in range(n)]
+    gsums = [torch.randn(K_) for _ in range(n)]
+    d = lambda lst: [t.to(dev) for t in lst]
+    dws = [torch.full((K_, Cin, R, R), float("nan"), device=dev) for _ in range(n)]
+    dgs = [torch.full((K_,), float("nan"), device=dev) for _ in range(n)]
+    dbs = [torch.full((K_,), float("nan"), device=dev) for _ in range(n)]
+    K.wgrad_finalize_batched(slabs.to(dev), d(ws), d(scales), d(rstds), d(means), d(gsums), dws, dgs, dbs, Cin)
+    torch.cuda.synchronize()
+    for i in range(n):
+        raw = slabs[i].double().sum(0)[..., :Cin].permute(0, 3, 1, 2)        # [K][Cin][R][S]
+        ref_dw = scales[i].double().view(-1, 1, 1, 1) * raw
+        ref_dg = rstds[i].double() * ((ws[i].double() * raw).sum((1, 2, 3)) - means[i].double() * gsums[i].double())
+        tol = 2e-5 * (1 + nsplit ** 0.5)
+        assert float((dws[i].cpu().double() - ref_dw).abs().max()) < tol * float(ref_dw.abs().max())
+        assert float((dgs[i].cpu().double() - ref_dg).abs().max()) < tol * float(ref_dg.abs().max()) + 1e-4
+        assert torch.equal(dbs[i].cpu(), gsums[i])
+    # without BN parameters (plain conv weights): dw only
+    dws2 = [torch.full((K_, Cin, R, R), float("nan"), device=dev) for _ in range(n)]
+    K.wgrad_finalize_batched(slabs.to(dev), None, None, None, None, None, dws2, None, None, Cin)
+    torch.cuda.synchronize()
+    for i in range(n):
+        raw = slabs[i].double().sum(0)[..., :Cin].permute(0, 3, 1, 2)
+        assert float((dws2[i].cpu().double() - raw).abs().max()) < 2e-5 * (1 + nsplit ** 0.5) * float(raw.abs().max())

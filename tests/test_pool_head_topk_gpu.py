@@ -226,3 +226,17 @@ def test_tile_gather_matches_get_tiles_totensor_normalize(dev):
         a = m(tiles.gather_tiles(torch.from_numpy(imgs).to(dev), ti[:16], rc[:16], 32, torch.float32))
         b = m(ref[:16].to(dev))
     assert float((a - b).abs().max()) < 1e-5
+
+
+def test_positive_bits_plane(dev):
+    """cs_positive_bits: bit (c & 7) of byte c >> 3 = x[..., c] > 0 (the mask operand the packed data gradients read)."""
+    torch.manual_seed(9)
+    x = torch.randn(3, 5, 7, 96)
+    x[x.abs() < 0.3] = 0.0
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1.0, -1.0, 3e38, -3e38])
+    xb = x.to(torch.bfloat16)
+    bits = K.positive_bits(xb.to(dev)).cpu()
+    assert bits.shape == (3, 5, 7, 12) and bits.dtype == torch.uint8
+    ref = (xb.float() > 0).view(3, 5, 7, 12, 8)
+    w = (2 ** torch.arange(8)).view(1, 1, 1, 1, 8)
+    assert torch.equal(bits.long(), (ref.long() * w).sum(-1))

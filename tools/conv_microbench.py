@@ -25,6 +25,10 @@ SHAPES = {
     "l4_1x1_2048_512": (64, 10, 10, 2048, 512, 1, 1, 0),
     "l1_1x1_256_64": (64, 75, 75, 256, 64, 1, 1, 0),
     "l3_1x1_1024_256": (64, 19, 19, 1024, 256, 1, 1, 0),
+    "l3_1x1_512_256": (64, 38, 38, 512, 256, 1, 1, 0),
+    "l4_1x1_1024_512": (64, 19, 19, 1024, 512, 1, 1, 0),
+    "l3_1x1_s2_512_1024": (64, 38, 38, 512, 1024, 1, 2, 0),
+    "l4_1x1_s2_1024_2048": (64, 19, 19, 1024, 2048, 1, 2, 0),
     "l2_3x3_s2": (64, 75, 75, 128, 128, 3, 2, 1),
     "dec_3x3_2048_1024": (8, 19, 19, 2048, 1024, 3, 1, 1),
 }
@@ -58,12 +62,15 @@ def main():
             wpk = K.pack_conv_weights(g, wk, False)
             resid = torch.randn((N, g.P, g.Q, Kc), device=dev).to(dt) if os.environ.get("RESID") else None
             cases.append(("fwd_pk", lambda: K.conv_fwd_packed(g, x, wpk, shift, resid, K.CS_ACT_RELU, want_bits=True)))
-            if resid is not None:
+            if resid is not None and cases and cases[0][0] == "fwd":
                 cases[0] = ("fwd", lambda: K.conv_fwd(g, x, wk, None, shift, resid, K.CS_ACT_RELU, want_bits=True))
         if dt == torch.bfloat16 and K.packed_supported(g, dt, True):
             wpd = K.pack_conv_weights(g, wc, True)
             mb = torch.randint(0, 255, (N, H, W, C // 8), dtype=torch.uint8, device=dev)
-            cases.append(("dgrad_pk", lambda: K.conv_dgrad_packed(g, dy, wpd, None, mb, want_colsum=True)))
+            if s == 1:
+                cases.append(("dgrad_pk", lambda: K.conv_dgrad_packed(g, dy, wpd, None, mb, want_colsum=True)))
+            else:
+                cases.append(("dgrad_pk", lambda: K.conv_dgrad_packed(g, dy, wpd)))          # compact strided gradient
         for kind, fn in cases:
             for _ in range(3):
                 fn()
