@@ -320,18 +320,27 @@ inline int fold_partial(const double* partial, int blocks, int C, double* out, h
     return 0;
 }
 
-inline int rows_per_block_for(long long M) {
+// rows per workgroup of the reductions: ~CELLSEG_BN_BLOCKS workgroups, but never fewer than 8 row steps per thread.  A thread owns one
+// 8-channel group and every rpar-th row (rpar = 256 / channel groups): with the old fixed floor of 64 rows a wide, small tensor
+// (EfficientNet stage 6/7: 6400 rows x 2304 channels) ran as 100 workgroups whose threads walked 64 rows one after the other.
+inline int rows_per_block_for(long long M, int C) {
     static const int target = cs_env_int_("CELLSEG_BN_BLOCKS", 1024);     // A/B experiments only
+    const int CG = C / 8 > 0 ? C / 8 : 1;
+    const int rpar = 256 / (CG < 256 ? CG : 256);
     long long r = (M + target - 1) / target;
-    if (r < 64) r = 64;
+    const long long floor_rows = 8LL * (rpar > 0 ? rpar : 1);
+    if (r < floor_rows) r = floor_rows;
     return (int)r;
 }
 
 // row block of the element-wise passes: ~CELLSEG_EW_BLOCKS (2048: 8 workgroups per compute unit) blocks, at least 16 rows each
-inline int ew_rows_per_block(long long M) {
+inline int ew_rows_per_block(long long M, int C) {
     static const int target = cs_env_int_("CELLSEG_EW_BLOCKS", 2048);       // A/B experiments only
+    const int CG = C / 8 > 0 ? C / 8 : 1;
+    const int rpar = 256 / (CG < 256 ? CG : 256);
     long long r = (M + target - 1) / target;
-    if (r < 16) r = 16;
+    const long long floor_rows = 4LL * (rpar > 0 ? rpar : 1);              // >= 2 two-row steps per thread
+    if (r < floor_rows) r = floor_rows;
     return (int)r;
 }
 
@@ -351,14 +360,14 @@ extern "C" int cs_bn_partial_fold(const double* partial, int rows, int C, double
 
 extern "C" size_t cs_bn_partial_workspace(long long M, int C) {
     if (M <= 0 || C <= 0) return 0;
-    const int rpb = rows_per_block_for(M);
+    const int rpb = rows_per_block_for(M, C);
     return (size_t)((M + rpb - 1) / rpb) * 2 * (size_t)C * sizeof(double);
 }
 
 extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream) {
     CS_CHECK_ARG(z && stats && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = rows_per_block_for(M);
+    const int rpb = rows_per_block_for(M, C);
     const int blocks = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, M, C, stats, rpb, workspace),
@@ -386,7 +395,7 @@ extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const fl
                            const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream) {
     CS_CHECK_ARG(z && y && mean && rstd && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = ew_rows_per_block(M);
+    const int rpb = ew_rows_per_block(M, C);
     const int grid = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, mean, rstd, gamma, beta,
@@ -403,7 +412,7 @@ extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const 
                                 void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = rows_per_block_for(M);
+    const int rpb = rows_per_block_for(M, C);
     const int blocks = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
@@ -424,7 +433,7 @@ extern "C" int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const f
                                float* dgamma, float* dbeta, void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && dz && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = ew_rows_per_block(M);
+    const int rpb = ew_rows_per_block(M, C);
     const int grid = (int)((M + rpb - 1) / rpb);
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,

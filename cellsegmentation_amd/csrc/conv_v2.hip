@@ -140,12 +140,6 @@ __device__ __forceinline__ void bload4(const i32x4& rsrc, unsigned voff, unsigne
                  ::"v"(voff), "s"(rsrc), "s"(soff), "i"(RB + 16 * J), "i"(RB + 16 * J + 3), "i"(RB + 16 * J + 4), "i"(RB + 16 * J + 7),
                  "i"(RB + 16 * J + 8), "i"(RB + 16 * J + 11), "i"(RB + 16 * J + 12), "i"(RB + 16 * J + 15));
 }
-// one of those four fragments (Q = 0..3): the ring kernel issues them one at a time between its MFMAs
-template <int J, int Q, int RB = R_B>
-__device__ __forceinline__ void bload1(const i32x4& rsrc, unsigned voff, unsigned soff) {
-    asm volatile("buffer_load_dwordx4 v[%c3:%c4], %0, %1, %2 offen offset:%c5"
-                 ::"v"(voff), "s"(rsrc), "s"(soff), "i"(RB + 16 * J + 4 * Q), "i"(RB + 16 * J + 4 * Q + 3), "i"(1024 * Q));
-}
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 template <int DST, int ADDR, unsigned OFF> __device__ __forceinline__ void lds_rd() {
     asm volatile("ds_read_b128 v[%c0:%c1], v[%c2] offset:%c3" ::"i"(DST), "i"(DST + 3), "i"(ADDR), "i"(OFF));
@@ -209,13 +203,10 @@ template <int TM, typename F> __device__ __forceinline__ void for_tiles(F&& f) {
 }
 
 struct NoTile { template <int I> __device__ __forceinline__ void operator()(const f32x16&) const {} };
-// called after MFMA number K (0 .. 3 * TM - 1) of the first three 16-deep steps: the ring kernel issues its next operand loads there
-struct NoHook { template <int K> __device__ __forceinline__ void operator()() const {} };
 
-template <int TM, int CUR, int S, unsigned STG, unsigned NSTG, bool COLD, bool AHEAD, bool SAME, bool FINAL = false, typename OnTile = NoTile,
-          typename Hook = NoHook>
+template <int TM, int CUR, int S, unsigned STG, unsigned NSTG, bool COLD, bool AHEAD, bool SAME, bool FINAL = false, typename OnTile = NoTile>
 __device__ __forceinline__ void tap_mfma(unsigned q0, unsigned q1, unsigned q2, unsigned q3, unsigned sh_cur, unsigned sh_next, unsigned hhb,
-                                         unsigned cf0, OnTile&& on_tile = NoTile{}, Hook&& hook = NoHook{}) {
+                                         unsigned cf0, OnTile&& on_tile = NoTile{}) {
     constexpr int A = R_AD + 4 * S, N = SAME ? A : R_AD + 4 * (1 - S);
     constexpr int F0 = R_AF, F1 = R_AF + 16;
     constexpr int B = R_B + 16 * CUR;
@@ -227,13 +218,13 @@ __device__ __forceinline__ void tap_mfma(unsigned q0, unsigned q1, unsigned q2, 
         for_tiles<TM>([&]<int i>() { lds_rd<F1 + 4 * i, A + i, STG + 512>(); });
     }
     if constexpr (AHEAD && !SAME) addr4<1 - S>(q0, q1, q2, q3, sh_next, hhb, cf0);
-    for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 0, F0 + 4 * i>(); lds_rd<F0 + 4 * i, A + i, STG + 1024>(); hook.template operator()<i>(); });
-    for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 4, F1 + 4 * i>(); lds_rd<F1 + 4 * i, A + i, STG + 1536>(); hook.template operator()<TM + i>(); });
+    for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 0, F0 + 4 * i>(); lds_rd<F0 + 4 * i, A + i, STG + 1024>(); });
+    for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 4, F1 + 4 * i>(); lds_rd<F1 + 4 * i, A + i, STG + 1536>(); });
     if constexpr (AHEAD) {
-        for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 8, F0 + 4 * i>(); lds_rd<F0 + 4 * i, N + i, NSTG>(); hook.template operator()<2 * TM + i>(); });
+        for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 8, F0 + 4 * i>(); lds_rd<F0 + 4 * i, N + i, NSTG>(); });
         for_tiles<TM>([&]<int i>() { wait_lgkm<W>(); mfma<R_ACC + 16 * i, B + 12, F1 + 4 * i>(); lds_rd<F1 + 4 * i, N + i, NSTG + 512>(); });
     } else {
-        for_tiles<TM>([&]<int i>() { wait_lgkm<W - i>(); mfma<R_ACC + 16 * i, B + 8, F0 + 4 * i>(); hook.template operator()<2 * TM + i>(); });
+        for_tiles<TM>([&]<int i>() { wait_lgkm<W - i>(); mfma<R_ACC + 16 * i, B + 8, F0 + 4 * i>(); });
         if constexpr (FINAL) {
             for_tiles<TM>([&]<int i>() {
                 wait_lgkm<TM - 1 - i>();
@@ -986,29 +977,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
     // prologue = steps -2 and -1 of the schedule
     issue_b.template operator()<0>(); issue_a(); advance_fetch();
     issue_b.template operator()<1>(); issue_a(); advance_fetch();
-    // Round 3 (ILV): the loads of step s+2 -- four weight fragments and the wave's two 16-row blocks -- are issued BETWEEN the MFMAs of
-    // step s (after MFMA 0..5) instead of in front of them: stamped, "weights + wait / barrier / DMA issue / MFMA" was 529 / 356 / 524 /
-    // 568-757 cycles per 64-deep step, i.e. ~1000 cycles of instruction issue sat on the critical path of every step of the deep
-    // contractions (16-32 steps per pixel tile: 1024 -> 256, 2048 -> 512).  Order inside a step: B0 A(block 0) B1 A(block 1) B2 B3;
-    // at the top of step s everything issued during step s-2 must have landed: 8 younger operations of step s-1 (+ epilogues).
-    constexpr bool ILV = !GA;
-    constexpr int LOOP_OPS = ILV ? 8 : 12;
-    auto issue_hook = [&]<int J>() {
-        return [&]<int Kx>() {
-            if constexpr (ILV && Kx < 6) {
-                const unsigned bv = (alive && f_mt != 0xffffffffu) ? (unsigned)lane * 16u : OOB;
-                const unsigned bs = w_base + (unsigned)f_c * 4096u;
-                const unsigned dst = smem_base + f_slot * SLOT;
-                if constexpr (Kx == 0) bload1<J, 0>(rsrc_b, bv, bs);
-                else if constexpr (Kx == 1) dma_block(rsrc_a, dst + (unsigned)wave * 2048u, f_vo[0], (unsigned)f_c * 128u);
-                else if constexpr (Kx == 2) bload1<J, 1>(rsrc_b, bv, bs);
-                else if constexpr (Kx == 3) dma_block(rsrc_a, dst + (unsigned)(wave + 4) * 2048u, f_vo[1], (unsigned)f_c * 128u);
-                else if constexpr (Kx == 4) bload1<J, 2>(rsrc_b, bv, bs);
-                else bload1<J, 3>(rsrc_b, bv, bs);
-            }
-        };
-    };
-
+    // (Round 3 tried issuing the loads of step s+2 BETWEEN the MFMAs of step s instead of in front of them -- B0 A0 B1 A1 B2 B3 after
+    // MFMA 0..5, vmcnt(8 + ...) -- to take the ~1000 cycles of issue that round 2's stamps showed off the critical path of the deep
+    // contractions.  All tests passed and nothing moved: 2048 -> 512 @10x10 26.4 vs 26.0 us, 1024 -> 256 @19x19 28.5 vs 28.6 us.  The
+    // stamps' own lgkmcnt(0) had serialised what they measured; removed again.)
     int c = 0;                        // chunk of the step being multiplied
     unsigned slot = 0;
     bool fin1 = false, fin2 = false;  // steps s-1 / s-2 ended with an epilogue
@@ -1021,26 +993,22 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
 #define CS_RTICK(k)
 #endif
     auto step = [&]<int CUR>() -> bool {
-        if constexpr (!ILV) issue_b.template operator()<(CUR + 2) % 3>();
+        issue_b.template operator()<(CUR + 2) % 3>();
         const int nfin = (int)fin1 + (int)fin2;
-        if (nfin == 0) wait_vm<LOOP_OPS>();
-        else if (nfin == 1) wait_vm<LOOP_OPS + E>();
-        else wait_vm<LOOP_OPS + 2 * E>();
+        if (nfin == 0) wait_vm<12>();
+        else if (nfin == 1) wait_vm<12 + E>();
+        else wait_vm<12 + 2 * E>();
         CS_RTICK(0);
         raw_barrier();
         CS_RTICK(1);
-        if constexpr (!ILV) {
-            issue_a();
-            advance_fetch();
-        }
-        auto hook = issue_hook.template operator()<(CUR + 2) % 3>();
+        issue_a();
+        advance_fetch();
         CS_RTICK(2);
         const unsigned sh_cur = slot * SLOT_ROWS;          // the slot, in LDS rows
         const bool fin = c == NCC - 1;
         bool more = true;
         if (!fin) {
-            tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, false>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0, NoTile{}, hook);
-            if constexpr (ILV) advance_fetch();
+            tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, false>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0);
             ++c;
             CS_RTICK(3);
         } else {
@@ -1054,8 +1022,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
                 else if (NCC == 2) wait_vm_mem<(E - 5 + 16 < 63 ? E - 5 + 16 : 63)>();
                 epi.template operator()<i>(d);
             };
-            tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, true>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0, on_tile, hook);
-            if constexpr (ILV) advance_fetch();
+            tap_mfma<TM, CUR, 0, 0u, 0u, true, false, true, true>(qb[0], qb[1], qb[2], qb[3], sh_cur, 0u, hhb, cf0, on_tile);
             epi.finish();
             vzero_seq(std::make_integer_sequence<int, 16 * TM>{});
             c = 0;
@@ -1215,24 +1182,17 @@ unsigned ring_groups(unsigned n_mt, unsigned n_ntiles, unsigned long long* cost_
     return best;
 }
 
-// Pixel-tile height of the 1 x 4 ring configuration (32 * TM pixels per workgroup tile).  The deep 1x1 layers of a bag of 64 tiles
-// have few tiles: 1024 -> 256 at 19 x 19 is 362 workgroup tiles of 128 px on 512 resident workgroups (150 compute units run ONE
-// workgroup), 2048 -> 512 at 10 x 10 only 200.  A workgroup's time ~ (pixel tiles it walks) x (TM x per-32-px work + a fixed
-// per-tile cost: ramp, epilogue issue, the steps' barriers), so fewer, shorter rounds win where the grid is not full; where every
-// workgroup walks many tiles the tall tile wins (weights re-streamed less often).  CELLSEG_RING_TM forces 2 / 3 / 4 (A/B runs).
+// Pixel-tile height of the 1 x 4 ring configuration (32 * TM pixels per workgroup tile; CELLSEG_RING_TM forces 2 / 3 / 4).  Measured per
+// shape (tools/ring_tm_sweep.sh, profiles/round3_notes.md): a deep contraction is a serial chain of NCC steps whose length hardly
+// depends on the tile height, so shorter tiles do NOT buy back an under-filled grid (2048 -> 512 @10x10, 200 tiles of 128 px on 512
+// resident workgroups: 26.0 us, 400 tiles of 64 px: 32.3 us).  The one case that wins is pick_tm's: all 128-px tiles resident but more
+// than one per compute unit somewhere, and the 96-px tiles still all resident (1024 -> 256 @19x19: 28.6 -> 26.0 us).
 int pick_ring_tm(long long M, int n_ntiles, int ncc) {
     static const int forced = cs_env_int_("CELLSEG_RING_TM", 0);
     if (forced >= 2 && forced <= 4) return forced;
-    int best = 4;
-    double best_t = 1e300;
-    for (int tm = 4; tm >= 2; --tm) {
-        unsigned long long tiles = 0;
-        ring_groups((unsigned)cs_ceil_div(M, 32 * tm), (unsigned)n_ntiles, &tiles);
-        // per workgroup tile: ncc steps of tm x 4 MFMA (+ a per-step cost that does not shrink with tm) + one epilogue of tm tiles
-        const double t = (double)tiles * (ncc * (tm + 1.5) + 2.0 * tm + 3.0);
-        if (t < best_t * 0.97) { best_t = t; best = tm; }      // a shorter tile has to win by 3 %
-    }
-    return best;
+    (void)ncc;
+    const long long wg4 = ((M + 127) / 128) * n_ntiles, wg3 = ((M + 95) / 96) * n_ntiles;
+    return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
 }
 
 bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {

@@ -348,6 +348,237 @@ __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const T* __restrict__
     for (int i = threadIdx.x; i < 2 * C; i += 256) partial[(long long)blockIdx.x * 2 * C + i] = (double)lsum[i];
 }
 
+// ---- Round 3: channel-tiled depthwise kernels for the filter sizes EfficientNet uses (k in {3,5}, stride in {1,2}, "same" padding).
+// The element-per-thread kernels above issue, per 16 bytes of output, k*k input loads AND 2*k*k weight loads through the vector L1
+// (a thread's channel group changes with its flat index, so the filter cannot stay in registers): 1.2 KB of L1 traffic per 16 bytes
+// stored -- L1-bound at ~0.9 TB/s on the EfficientNet-B3 step.  Here a workgroup is 32 channel groups (256 channels) x 8 pixel lanes:
+//   * the filter slice [k*k][256] sits in LDS (25.6 KB for k = 5; both pixel lanes of a wave read the same address: broadcast);
+//   * a thread produces TWO neighbouring output columns (forward / stride-1 gradient) or a 2 x 2 block of input pixels (stride-2
+//     gradient) from one register window, so a 5x5 stride-1 output costs 15 input loads instead of 25 (+50 weight loads);
+//   * the stride-2 data gradient is the gather form per 2 x 2 block: every (tap, output parity) pair is a compile-time constant and
+//     each of the k*k taps is multiplied exactly once per block (the generic kernel walks k*k taps per pixel and rejects 3/4 of them).
+constexpr int kDwCGT = 32;       // at most 32 channel groups per workgroup; the actual tile width cgt = ceil(CG / chunks) is a launch
+                                 // argument and the workgroup runs 256 / cgt pixel lanes (EfficientNet-B3's depthwise layers have 5, 18, 24,
+                                 // 36, 72, 102, 174 and 288 channel groups: a fixed 32-wide tile would idle 84 % of the lanes on the first)
+
+template <int R, bool FLIP>
+__device__ __forceinline__ void dw_stage_filter(const float* __restrict__ w, int C, int cg_base, int cgt, float (*wl)[kDwCGT][8]) {
+    const int CG = C / 8;
+    for (int i = threadIdx.x; i < R * R * cgt; i += 256) {
+        const int tap = i / cgt, c_ = i - tap * cgt;
+        const int cgx = cg_base + c_;
+        float v[8];
+        if (cgx < CG) load8p(w + (long long)(FLIP ? R * R - 1 - tap : tap) * C + cgx * 8, 0.f, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wl[tap][c_][e] = v[e];
+    }
+}
+
+// forward (FLIP = false) and stride-1 data gradient (FLIP = true, pad' = R - 1 - pad, source = dy): two output columns per thread.
+// STATS: per-channel sum / sum of squares of the STORED values, one partial row per pixel block: partial[(2 * blockIdx.x + {0,1}) * C + c].
+template <typename T, int R, int ST, bool STATS, bool FLIP>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int act, T* __restrict__ y,
+                                                      double* __restrict__ partial, int N, int H, int W, int C, int pad, int P, int Q,
+                                                      int items_per_block, int cgt) {
+    __shared__ float wl[R * R][kDwCGT][8];
+    __shared__ float fold[STATS ? 2 : 1][STATS ? 256 : 1][8];
+    const int npl = 256 / cgt;                       // pixel lanes
+    const int cgl = threadIdx.x % cgt, pl = threadIdx.x / cgt;
+    const int CG = C / 8;
+    const int cg = blockIdx.y * cgt + cgl;
+    const bool live = cg < CG && pl < npl;
+    dw_stage_filter<R, FLIP>(w, C, blockIdx.y * cgt, cgt, wl);
+    __syncthreads();
+    constexpr int NC = ST + R;                       // input columns of the two outputs' window
+    const int Qp = (Q + 1) / 2;
+    const long long total = (long long)N * P * Qp;
+    const long long i0 = (long long)blockIdx.x * items_per_block;
+    long long i1 = i0 + items_per_block;
+    if (i1 > total) i1 = total;
+    float sc8[8], sh8[8], s1[8], s2[8];
+    if (live) {
+        load8p(scale ? scale + cg * 8 : nullptr, 1.f, sc8);
+        load8p(shift ? shift + cg * 8 : nullptr, 0.f, sh8);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (live) {
+        for (long long it = i0 + pl; it < i1; it += npl) {
+            const int oxp = (int)(it % Qp);
+            const long long t = it / Qp;
+            const int oy = (int)(t % P);
+            const long long n = t / P;
+            const int ox0 = 2 * oxp;
+            const bool two = ox0 + 1 < Q;
+            float a0[8], a1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+            const int ixb = ox0 * ST - pad;
+#pragma unroll
+            for (int kh = 0; kh < R; ++kh) {
+                const int iy = oy * ST - pad + kh;
+                if ((unsigned)iy < (unsigned)H) {
+                    const T* rowp = x + ((n * H + iy) * (long long)W) * C + cg * 8;
+                    float xv[NC][8];
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        const int ix = ixb + j;
+                        if ((unsigned)ix < (unsigned)W) load8<T>(rowp + (long long)ix * C, xv[j]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) xv[j][e] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < R; ++kw) {
+                        const float4 wa = *reinterpret_cast<const float4*>(&wl[kh * R + kw][cgl][0]);
+                        const float4 wb = *reinterpret_cast<const float4*>(&wl[kh * R + kw][cgl][4]);
+                        const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { a0[e] += xv[kw][e] * wv[e]; a1[e] += xv[kw + ST][e] * wv[e]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v0 = a0[e] * sc8[e] + sh8[e], v1 = a1[e] * sc8[e] + sh8[e];
+                if (act == CS_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                else if (act == CS_ACT_SILU) { v0 = v0 / (1.f + __expf(-v0)); v1 = v1 / (1.f + __expf(-v1)); }
+                a0[e] = v0; a1[e] = v1;
+            }
+            T* orow = y + ((n * P + oy) * (long long)Q + ox0) * C + cg * 8;
+            store8<T>(orow, a0);
+            if (two) store8<T>(orow + C, a1);
+            if constexpr (STATS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r0 = to_f32<T>(from_f32<T>(a0[e]));       // statistics of the stored (rounded) values
+                    const float r1 = two ? to_f32<T>(from_f32<T>(a1[e])) : 0.f;
+                    s1[e] += r0 + r1; s2[e] += r0 * r0 + r1 * r1;
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { fold[0][threadIdx.x][e] = s1[e]; fold[1][threadIdx.x][e] = s2[e]; }
+        __syncthreads();
+        if (pl == 0 && live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                double t0 = 0.0, t1 = 0.0;
+                for (int r = 0; r < npl; ++r) { t0 += (double)fold[0][r * cgt + cgl][e]; t1 += (double)fold[1][r * cgt + cgl][e]; }
+                partial[(2LL * blockIdx.x) * C + cg * 8 + e] = t0;
+                partial[(2LL * blockIdx.x + 1) * C + cg * 8 + e] = t1;
+            }
+        }
+    }
+}
+
+// stride-2 data gradient, pad = (R - 1) / 2: a thread owns the 2 x 2 block of input pixels (2a + i, 2b + j); it reads the
+// NW x NW window of dy rows a - (NW - 2) .. a + 1 (NW = (R + 1) / 2) and multiplies tap kh = i + pad + 2 * (NW - 2 - wy) (same in x)
+// where that index is a tap of the filter -- all compile-time.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int N,
+                                                          int H, int W, int C, int P, int Q, int items_per_block, int cgt) {
+    __shared__ float wl[R * R][kDwCGT][8];
+    constexpr int PAD = (R - 1) / 2, NW = (R + 1) / 2;
+    const int npl = 256 / cgt;
+    const int cgl = threadIdx.x % cgt, pl = threadIdx.x / cgt;
+    const int CG = C / 8;
+    const int cg = blockIdx.y * cgt + cgl;
+    dw_stage_filter<R, false>(w, C, blockIdx.y * cgt, cgt, wl);
+    __syncthreads();
+    if (cg >= CG || pl >= npl) return;
+    const int Ha = (H + 1) / 2, Wb = (W + 1) / 2;
+    const long long total = (long long)N * Ha * Wb;
+    const long long i0 = (long long)blockIdx.x * items_per_block;
+    long long i1 = i0 + items_per_block;
+    if (i1 > total) i1 = total;
+    for (long long it = i0 + pl; it < i1; it += npl) {
+        const int b = (int)(it % Wb);
+        const long long t = it / Wb;
+        const int a = (int)(t % Ha);
+        const long long n = t / Ha;
+        float acc[2][2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < NW; ++wy) {
+            const int oy = a - (NW - 2) + wy;
+            if ((unsigned)oy >= (unsigned)P) continue;
+#pragma unroll
+            for (int wx = 0; wx < NW; ++wx) {
+                const int ox = b - (NW - 2) + wx;
+                if ((unsigned)ox >= (unsigned)Q) continue;
+                float g[8];
+                load8<T>(dy + ((n * P + oy) * (long long)Q + ox) * C + cg * 8, g);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int kh = i + PAD + 2 * (NW - 2 - wy);
+                    if (kh < 0 || kh >= R) continue;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int kw = j + PAD + 2 * (NW - 2 - wx);
+                        if (kw < 0 || kw >= R) continue;
+                        const float4 wa = *reinterpret_cast<const float4*>(&wl[kh * R + kw][cgl][0]);
+                        const float4 wb = *reinterpret_cast<const float4*>(&wl[kh * R + kw][cgl][4]);
+                        const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][j][e] += g[e] * wv[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = 2 * a + i;
+            if (iy >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ix = 2 * b + j;
+                if (ix < W) store8<T>(dx + ((n * H + iy) * (long long)W + ix) * C + cg * 8, acc[i][j]);
+            }
+        }
+    }
+}
+
+// channel-group tile of the tiled kernels: chunks = ceil(CG / 32) workgroup columns of cgt = ceil(CG / chunks) channel groups
+inline void dw_tile_shape(int C, int& chunks, int& cgt) {
+    const int CG = C / 8;
+    chunks = (CG + kDwCGT - 1) / kDwCGT;
+    cgt = (CG + chunks - 1) / chunks;
+}
+// work items per workgroup of the tiled kernels: ~2048 workgroups in all, at least 4 items per pixel lane
+inline int dw_tile_items(long long items, int chunks, int cgt) {
+    long long blocks = 2048 / (chunks > 0 ? chunks : 1);
+    if (blocks < 1) blocks = 1;
+    long long per = (items + blocks - 1) / blocks;
+    const int npl = 256 / cgt;
+    if (per < 4 * npl) per = 4 * npl;
+    return (int)per;
+}
+// Which launches take the tiled kernels: measured per EfficientNet-B3 layer (tools/dw_microbench.py, profiles/round3_notes.md).
+// Both families are VALU-bound, not L1-bound as assumed (k = 5 layers: 25 multiply-adds + the bf16 unpacking per output element run
+// at 0.45-0.8 TB/s either way), so the tile only pays where it removes work: every stride-2 data gradient (2-3x: 286 -> 176, 186 ->
+// 62, 39 -> 18, 52 -> 25 us), the 3x3 stride-1 forwards (180 -> 138, 58 -> 47, 56 -> 34, 77 -> 49 us) and the narrow early layers.
+inline bool dw_tiled_geometry(const CsConvGeom* g, int kind /* 0 forward, 1 data gradient */) {
+    static const int off = cs_env_int_("CELLSEG_DW_UNTILED", 0);      // A/B experiments only: 1 = the element-per-thread kernels
+    if (off || !((g->R == 3 || g->R == 5) && (g->stride == 1 || g->stride == 2) && g->pad == (g->R - 1) / 2)) return false;
+    if (off == 2) return true;                                        // (2 = tiled wherever the geometry allows)
+    if (kind == 1) return g->stride == 2 || g->C <= 48;
+    return g->R == 3 && (g->stride == 1 || g->C >= 288);
+}
+
 inline int grid_ew(long long total) {
     long long b = (total + 255) / 256;
     if (b > 16384) b = 16384;
@@ -360,6 +591,33 @@ inline int grid_ew(long long total) {
 #define CS_T_SWITCH(dtype, NAME, F32, BF16)                                            \
     if (dtype == CS_F32) { F32; } else if (dtype == CS_BF16) { BF16; }                 \
     else { cs_set_error_(NAME ": bad dtype"); return CS_ERR_INVALID_ARG; }
+
+// launch of dw_tile_kernel<T, R, ST, STATS, FLIP> on (source x [N][H][W][C]) -> (y [N][P][Q][C])
+template <typename T, bool STATS, bool FLIP>
+static void launch_dw_tile(int R, int ST, hipStream_t st, const void* x, const float* w, const float* scale, const float* shift, int act,
+                           void* y, double* partial, int N, int H, int W, int C, int pad, int P, int Q, int* rows_out) {
+    int chunks, cgt;
+    dw_tile_shape(C, chunks, cgt);
+    const long long items = (long long)N * P * ((Q + 1) / 2);
+    const int per = dw_tile_items(items, chunks, cgt);
+    dim3 grid((unsigned)((items + per - 1) / per), (unsigned)chunks);
+    if (rows_out) *rows_out = (int)grid.x;
+#define CS_DW_TILE(R_, S_)                                                                                                      \
+    hipLaunchKernelGGL((dw_tile_kernel<T, R_, S_, STATS, FLIP>), grid, dim3(256), 0, st, (const T*)x, w, scale, shift, act, (T*)y, partial, \
+                       N, H, W, C, pad, P, Q, per, cgt)
+    if (R == 3 && ST == 1) CS_DW_TILE(3, 1);
+    else if (R == 3) CS_DW_TILE(3, 2);
+    else if (ST == 1) CS_DW_TILE(5, 1);
+    else CS_DW_TILE(5, 2);
+#undef CS_DW_TILE
+}
+static int dw_tile_rows(const CsConvGeom* g) {
+    int chunks, cgt;
+    dw_tile_shape(g->C, chunks, cgt);
+    const long long items = (long long)g->N * g->P * ((g->Q + 1) / 2);
+    const int per = dw_tile_items(items, chunks, cgt);
+    return (int)((items + per - 1) / per);
+}
 
 static int check_dw(const CsConvGeom* g, const char* what) {
     if (!g || g->R != g->S || g->R < 1 || g->C % 8 != 0 || g->K != g->C || g->stride < 1 ||
@@ -376,6 +634,12 @@ extern "C" int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     if (rc) return rc;
     CS_CHECK_ARG(x && w_hwc && y, "dwconv_fwd: NULL tensor");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_tiled_geometry(g, 0) && (dtype == CS_F32 || dtype == CS_BF16)) {
+        if (dtype == CS_F32) launch_dw_tile<float, false, false>(g->R, g->stride, st, x, w_hwc, scale, shift, act, y, nullptr, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, nullptr);
+        else launch_dw_tile<bf16_t, false, false>(g->R, g->stride, st, x, w_hwc, scale, shift, act, y, nullptr, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, nullptr);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     const int grid = grid_ew((long long)g->N * g->P * g->Q * (g->C / 8));
     CS_T_SWITCH(dtype, "dwconv_fwd",
                 hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, w_hwc, scale, shift, act, (float*)y,
@@ -401,6 +665,7 @@ static int dw_stats_grid(const CsConvGeom* g) {
 
 extern "C" size_t cs_dwconv_fwd_stats_workspace(const CsConvGeom* g) {
     if (!g || g->C <= 0 || g->C % 8) return 0;
+    if (dw_tiled_geometry(g, 0)) return (size_t)dw_tile_rows(g) * 2 * (size_t)g->C * sizeof(double);
     return (size_t)dw_stats_grid(g) * 2 * (size_t)g->C * sizeof(double);
 }
 
@@ -409,8 +674,14 @@ extern "C" int cs_dwconv_fwd_stats(const CsConvGeom* g, int dtype, const void* x
     int rc = check_dw(g, "dwconv_fwd_stats: bad geometry (square filter, K == C, C % 8 == 0 required)");
     if (rc) return rc;
     CS_CHECK_ARG(x && w_hwc && y && partial && partial_rows, "dwconv_fwd_stats: NULL argument");
-    CS_CHECK_ARG((size_t)2 * g->C * sizeof(float) <= 65536, "dwconv_fwd_stats: too many channels for the LDS fold");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_tiled_geometry(g, 0) && (dtype == CS_F32 || dtype == CS_BF16)) {
+        if (dtype == CS_F32) launch_dw_tile<float, true, false>(g->R, g->stride, st, x, w_hwc, nullptr, nullptr, CS_ACT_NONE, y, partial, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, partial_rows);
+        else launch_dw_tile<bf16_t, true, false>(g->R, g->stride, st, x, w_hwc, nullptr, nullptr, CS_ACT_NONE, y, partial, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, partial_rows);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
+    CS_CHECK_ARG((size_t)2 * g->C * sizeof(float) <= 65536, "dwconv_fwd_stats: too many channels for the LDS fold");
     const int grid = dw_stats_grid(g);
     const size_t lds = (size_t)2 * g->C * sizeof(float);
     *partial_rows = grid;
@@ -428,6 +699,25 @@ extern "C" int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     if (rc) return rc;
     CS_CHECK_ARG(dy && w_hwc && dx, "dwconv_dgrad: NULL tensor");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_tiled_geometry(g, 1) && (dtype == CS_F32 || dtype == CS_BF16)) {
+        if (g->stride == 1) {
+            // the gradient of a stride-1 "same" convolution is the same convolution with the filter mirrored (source dy, destination dx)
+            if (dtype == CS_F32) launch_dw_tile<float, false, true>(g->R, 1, st, dy, w_hwc, nullptr, nullptr, CS_ACT_NONE, dx, nullptr, g->N, g->P, g->Q, g->C, g->R - 1 - g->pad, g->H, g->W, nullptr);
+            else launch_dw_tile<bf16_t, false, true>(g->R, 1, st, dy, w_hwc, nullptr, nullptr, CS_ACT_NONE, dx, nullptr, g->N, g->P, g->Q, g->C, g->R - 1 - g->pad, g->H, g->W, nullptr);
+        } else {
+            int chunks, cgt;
+            dw_tile_shape(g->C, chunks, cgt);
+            const long long items = (long long)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2);
+            const int per = dw_tile_items(items, chunks, cgt);
+            dim3 grid((unsigned)((items + per - 1) / per), (unsigned)chunks);
+#define CS_DW_S2(T_, R_) hipLaunchKernelGGL((dw_dgrad_s2_kernel<T_, R_>), grid, dim3(256), 0, st, (const T_*)dy, w_hwc, (T_*)dx, g->N, g->H, g->W, g->C, g->P, g->Q, per, cgt)
+            if (dtype == CS_F32) { if (g->R == 3) CS_DW_S2(float, 3); else CS_DW_S2(float, 5); }
+            else { if (g->R == 3) CS_DW_S2(bf16_t, 3); else CS_DW_S2(bf16_t, 5); }
+#undef CS_DW_S2
+        }
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     const int grid = grid_ew((long long)g->N * g->H * g->W * (g->C / 8));
     CS_T_SWITCH(dtype, "dwconv_dgrad",
                 hipLaunchKernelGGL(dw_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, w_hwc, (float*)dx, g->N, g->H,

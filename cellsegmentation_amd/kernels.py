@@ -600,7 +600,7 @@ def bn_stats(z, stats=None):
 
 def _bn_ws(M, C, device):
     """Partial-sum workspace of the BN reductions (None for small row counts: a few workgroups, atomics are fine)."""
-    if M < 16384:
+    if M < 2048:
         return None
     return torch.empty((_lib.load().cs_bn_partial_workspace(M, C) // 8,), dtype=torch.float64, device=device)
 

@@ -200,3 +200,72 @@ def test_one_launch_staging_writes_the_packed_operands_bit_exactly(shape, dev):
     assert torch.equal(w_b.view(-1).view(torch.int16), ref_b.view(-1).view(torch.int16)[: w_b.numel()])
     assert float((scale - scale_ref).abs().max()) < 1e-6
     assert torch.equal(u_f.view(torch.int16), w_khwc.view(torch.int16)) and torch.equal(u_b.view(torch.int16), w_chwk.view(torch.int16))
+
+
+def _sparse_pm1(shape, per_row, g):
+    """[rows, ...] tensor with `per_row` entries of +-1 / +-2 per leading index, zeros elsewhere."""
+    rows = shape[0]
+    flat = int(torch.tensor(shape[1:]).prod())
+    w = torch.zeros((rows, flat))
+    for r in range(rows):
+        idx = torch.randperm(flat, generator=g)[:per_row]
+        w[r, idx] = torch.randint(1, 3, (per_row,), generator=g).float() * (torch.randint(0, 2, (per_row,), generator=g).float() * 2 - 1)
+    return w.view(shape)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_packed_kernels_are_exact_on_integer_data(shape, dev):
+    """a loose 1e-2 band cannot see one wrong tap among 2048 channels.  With small-integer operands every partial
+    sum is an integer below 2^24, so fp32 accumulation is EXACT in any order, and with sparse +-1 / +-2 weights every result is an
+    integer of magnitude < 256, which bf16 stores exactly: the packed forward / data gradient must equal torch's fp32 convolution
+    BIT FOR BIT (residual, shift, ReLU, add and mask included), and a single mis-indexed tap, channel, chunk or pixel changes an
+    output integer.  The dense weight gradients (fp32 slabs) are exact the same way."""
+    N, H, W, Cin, Cout, R, stride, pad = shape
+    g = torch.Generator().manual_seed(1234 + H * 5 + Cin + Cout + R)
+    x = torch.randint(-4, 5, (N, Cin, H, W), generator=g).float()
+    w = _sparse_pm1((Cout, Cin, R, R), 12, g)                                # forward sums: <= 12 * 2 * 4 = 96
+    geom = K.make_geom(N, H, W, Cin, Cout, R, R, stride, pad)
+    P, Q = geom.P, geom.Q
+    w_khwc, w_chwk = K.weight_prep(w.to(dev), None, BF, Cin, Cout, want_fwd=True, want_bwd=True)
+    xd = _nhwc(x, dev)
+    if K.packed_supported(geom, BF, dgrad=False):
+        shift = torch.randint(-8, 9, (Cout,), generator=g).float()
+        res = torch.randint(-16, 17, (N, Cout, P, Q), generator=g).float()
+        ref = F.conv2d(x, w, stride=stride, padding=pad)
+        ref_full = torch.relu(ref + shift.view(1, -1, 1, 1) + res)
+        assert float(ref_full.abs().max()) <= 256 and float(ref.abs().max()) <= 256
+        wp = K.pack_conv_weights(geom, w_khwc, dgrad=False)
+        y_plain = K.conv_fwd_packed(geom, xd, wp)
+        y_full, bits = K.conv_fwd_packed(geom, xd, wp, shift.to(dev), _nhwc(res, dev), K.CS_ACT_RELU, want_bits=True)
+        torch.cuda.synchronize()
+        assert torch.equal(_from_nhwc(y_plain), ref), f"max diff {float((_from_nhwc(y_plain) - ref).abs().max())}"
+        assert torch.equal(_from_nhwc(y_full), ref_full)
+        assert torch.equal(_unpack_bits(bits, Cout), ref_full > 0)
+    if stride == 1 and K.packed_supported(geom, BF, dgrad=True):
+        # the data gradient contracts over (k, taps): sparse per INPUT channel
+        wt = _sparse_pm1((Cin, Cout, R, R), 12, g).permute(1, 0, 2, 3).contiguous()
+        _, wt_chwk = K.weight_prep(wt.to(dev), None, BF, Cin, Cout, want_fwd=False, want_bwd=True)
+        dy = torch.randint(-4, 5, (N, Cout, P, Q), generator=g).float()
+        add = torch.randint(-16, 17, (N, Cin, H, W), generator=g).float()
+        mask = torch.rand((N, Cin, H, W), generator=g) > 0.4
+        ref_dx = torch.nn.grad.conv2d_input((N, Cin, H, W), wt, dy, stride=stride, padding=pad)
+        ref_dx2 = (ref_dx + add) * mask
+        assert float(ref_dx2.abs().max()) <= 256 and float(ref_dx.abs().max()) <= 256
+        dyd = _nhwc(dy, dev)
+        wpd = K.pack_conv_weights(geom, wt_chwk, dgrad=True)
+        dx = K.conv_dgrad_packed(geom, dyd, wpd)
+        dx2, pc = K.conv_dgrad_packed(geom, dyd, wpd, add=_nhwc(add, dev), mask_bits=_pack_bits(mask, dev), want_colsum=True)
+        cs = pc.vector()
+        torch.cuda.synchronize()
+        assert torch.equal(_from_nhwc(dx), ref_dx), f"max diff {float((_from_nhwc(dx) - ref_dx).abs().max())}"
+        assert torch.equal(_from_nhwc(dx2), ref_dx2)
+        assert torch.equal(cs.cpu()[:Cin], ref_dx2.sum(dim=(0, 2, 3)))       # integer column sums below 2^24: exact too
+    # weight gradients (first- and second-generation kernels; fp32 output, dense integer operands)
+    dyw = torch.randint(-3, 4, (N, Cout, P, Q), generator=g).float()
+    ref_dw = torch.nn.grad.conv2d_weight(x, (Cout, Cin, R, R), dyw, stride=stride, padding=pad)
+    assert float(ref_dw.abs().max()) < 2 ** 24
+    slabs = K.wgrad_batched(geom, [xd, xd], [_nhwc(dyw, dev)] * 2)
+    torch.cuda.synchronize()
+    for i in range(2):
+        got = slabs[i].double().sum(0).float().cpu().permute(0, 3, 1, 2)     # [K][R][S][C] -> [K][C][R][S]
+        assert torch.equal(got, ref_dw), f"wgrad item {i}: max diff {float((got - ref_dw).abs().max())}"

@@ -29,7 +29,8 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(24, 3, 1, 15, 14), (40, 5, 2, 19, 19), (16, 3, 2, 10, 11), (48, 5, 1, 9, 9),
-                                 (528, 5, 1, 21, 19), (1032, 3, 2, 12, 13)])
+                                 (528, 5, 1, 21, 19), (1032, 3, 2, 12, 13), (264, 5, 2, 12, 11), (72, 3, 1, 1, 7), (8, 5, 2, 2, 3),
+                                 (32, 7, 1, 9, 9)])
 def test_depthwise_conv(cfg, dtype, dev):
     C, k, s, H, W = cfg
     torch.manual_seed(C + k)
@@ -52,6 +53,12 @@ def test_depthwise_conv(cfg, dtype, dev):
     assert _rel(_nchw(dxd), x.grad) < tol
     assert _rel(dwd.permute(2, 0, 1).unsqueeze(1).cpu(), w.grad) < 1e-4
     assert _rel(_nchw(yf), F.silu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))) < tol
+    # the train-mode forward: the same z plus the batch statistics of the STORED values (fp64 sum / sum of squares per channel)
+    zs, stats = K.dwconv_fwd_stats(g, xd, w_hwc)
+    torch.cuda.synchronize()
+    assert torch.equal(zs, yd)
+    zf = zs.double().cpu().reshape(-1, C)
+    assert _rel(stats[0].cpu(), zf.sum(0)) < 1e-5 and _rel(stats[1].cpu(), (zf * zf).sum(0)) < 1e-5
 
 
 def test_se_and_rowscale(dev):
@@ -203,3 +210,18 @@ def test_stochastic_depth_row_mode_vs_oracle(dev):
         worst.append((float((g - r).abs().max() / max(float(r.abs().max()), 1e-3 * gmax)), k))
     worst.sort(reverse=True)
     assert worst[0][0] < 5e-3, worst[:5]
+
+
+def test_depthwise_tiled_kernels_everywhere_the_geometry_allows(dev):
+    """The launch rule (csrc/dwse.hip: dw_tiled_geometry) sends only part of the 3x3 / 5x5 launches to the channel-tiled kernels;
+    CELLSEG_DW_UNTILED=2 forces them wherever the geometry allows, =1 forces the element-per-thread kernels.  Both extremes must
+    pass the same per-op parity test (the knob is read once per process: child interpreters)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("2", "1"):
+        env = dict(os.environ, CELLSEG_DW_UNTILED=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_efficientnet_gpu.py"), "-m", "gpu", "-x", "-q",
+                            "-k", "test_depthwise_conv"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
