@@ -249,6 +249,76 @@ __global__ __launch_bounds__(256) void se_ds_kernel(const T* __restrict__ dy, co
     }
 }
 
+// out[n][c] += scale * sum over this workgroup's rows of a (* b): grid = (row blocks of ONE sample, N); a thread keeps one
+// 8-channel group and every rpar-th row (the BN reductions' layout: all 256 lanes busy for any channel count -- the 64-group x 4-lane
+// workgroups of se_ds_kernel / gap_fwd_kernel idle 72 % of their lanes on a 144-channel tensor), two rows in flight; LDS fold, one
+// float atomic per (workgroup, channel) into the zeroed output.
+template <typename T, bool PROD>
+__global__ __launch_bounds__(256) void sample_rowsum_kernel(const T* __restrict__ a, const T* __restrict__ b, float scale, float* __restrict__ out,
+                                                            int HW, int C, int rows_per_block) {
+    __shared__ float red[256][8];
+    const int CG = C / 8;
+    const int n = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > HW) r1 = HW;
+    const T* an = a + (long long)n * HW * C;
+    const T* bn = PROD ? b + (long long)n * HW * C : nullptr;
+    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
+        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+        const int rpar = 256 / width;
+        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int rr = threadIdx.x / width;
+        const bool live = rr < rpar;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (live) {
+            int r = r0 + rr;
+            for (; r + rpar < r1; r += 2 * rpar) {
+                float v0[8], v1[8];
+                load8<T>(an + (long long)r * C + cg * 8, v0);
+                load8<T>(an + (long long)(r + rpar) * C + cg * 8, v1);
+                if constexpr (PROD) {
+                    float w0[8], w1[8];
+                    load8<T>(bn + (long long)r * C + cg * 8, w0);
+                    load8<T>(bn + (long long)(r + rpar) * C + cg * 8, w1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v0[e] * w0[e] + v1[e] * w1[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v0[e] + v1[e];
+                }
+            }
+            if (r < r1) {
+                float v0[8];
+                load8<T>(an + (long long)r * C + cg * 8, v0);
+                if constexpr (PROD) {
+                    float w0[8];
+                    load8<T>(bn + (long long)r * C + cg * 8, w0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v0[e] * w0[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v0[e];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = live ? acc[e] : 0.f;
+        __syncthreads();
+        // one atomic per (workgroup, channel), consecutive lanes on consecutive channels (256 contiguous bytes per wave-instruction: the
+        // full-rate shape of MI355X_MICROARCH "Global float atomics"; 8 atomics per lane at a 32-byte lane stride ran 2x slower)
+        for (int idx = threadIdx.x; idx < width * 8; idx += 256) {
+            const int cl = idx >> 3, e = idx & 7;
+            float t = 0.f;
+            for (int q = 0; q < rpar; ++q) t += red[q * width + cl][e];
+            atomicAdd(out + (long long)n * C + (cg0 + cl) * 8 + e, t * scale);
+        }
+    }
+}
+
 // dx[n,p,c] = dy[n,p,c] * s[n,c] + davg[n,c] / HW        (davg nullable)
 template <typename T>
 __global__ __launch_bounds__(256) void se_dx_kernel(const T* __restrict__ dy, const float* __restrict__ s, const float* __restrict__ davg,
@@ -778,6 +848,31 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     return CS_OK;
 }
 
+int cs_sample_rowsum_(const void* a, const void* b, int dtype, float scale, float* out, int N, int HW, int C, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) { cs_set_error_("sample_rowsum: memset failed"); return CS_ERR_LAUNCH; }
+    // ~2048 workgroups over the N samples, at least 8 row steps per thread
+    const int CG = C / 8;
+    const int rpar = 256 / (CG < 256 ? CG : 256);
+    int per_sample = 2048 / N;
+    if (per_sample < 1) per_sample = 1;
+    int rpb = (HW + per_sample - 1) / per_sample;
+    if (rpb < 8 * rpar) rpb = 8 * rpar;
+    dim3 grid((unsigned)((HW + rpb - 1) / rpb), (unsigned)N);
+    if (dtype == CS_F32) {
+        if (b) hipLaunchKernelGGL((sample_rowsum_kernel<float, true>), grid, dim3(256), 0, st, (const float*)a, (const float*)b, scale, out, HW, C, rpb);
+        else hipLaunchKernelGGL((sample_rowsum_kernel<float, false>), grid, dim3(256), 0, st, (const float*)a, (const float*)nullptr, scale, out, HW, C, rpb);
+    } else if (dtype == CS_BF16) {
+        if (b) hipLaunchKernelGGL((sample_rowsum_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, scale, out, HW, C, rpb);
+        else hipLaunchKernelGGL((sample_rowsum_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)nullptr, scale, out, HW, C, rpb);
+    } else {
+        cs_set_error_("sample_rowsum: bad dtype");
+        return CS_ERR_INVALID_ARG;
+    }
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
 extern "C" int cs_se_scale(const void* x, int dtype, const float* s, void* y, int N, int HW, int C, void* stream) {
     CS_CHECK_ARG(x && s && y && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -796,14 +891,7 @@ extern "C" int cs_se_scale_bwd(const void* dy, const void* x, int dtype, const f
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (phase == 0) {
         CS_CHECK_ARG(x && ds, "se_scale_bwd: phase 0 needs x and ds");
-        int slabs = (HW + 511) / 512;
-        if (slabs > 64) slabs = 64;
-        const int slab = (HW + slabs - 1) / slabs;
-        if (hipMemsetAsync(ds, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) { cs_set_error_("se_scale_bwd: memset failed"); return CS_ERR_LAUNCH; }
-        dim3 grid((C / 8 + 63) / 64, N, (HW + slab - 1) / slab);
-        CS_T_SWITCH(dtype, "se_scale_bwd",
-                    hipLaunchKernelGGL(se_ds_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, ds, HW, C, slab),
-                    hipLaunchKernelGGL(se_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, ds, HW, C, slab));
+        return cs_sample_rowsum_(dy, x, dtype, 1.f, ds, N, HW, C, stream);
     } else {
         CS_CHECK_ARG(s && dx, "se_scale_bwd: phase 1 needs s and dx");
         const int grid = grid_ew((long long)N * HW * (C / 8));

@@ -225,3 +225,21 @@ def test_depthwise_tiled_kernels_everywhere_the_geometry_allows(dev):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_efficientnet_gpu.py"), "-m", "gpu", "-x", "-q",
                             "-k", "test_depthwise_conv"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(3, 19, 19, 144), (2, 10, 10, 2304), (4, 75, 38, 40), (2, 8, 8, 24), (1, 30, 31, 2136)])
+def test_per_sample_reductions_of_the_se_block(cfg, dtype, dev):
+    """cs_sample_rowsum_ behind cs_gap_avgmax_fwd(with_max = 0) and cs_se_scale_bwd(phase 0): average pool and ds = sum_p dy * x per
+    (sample, channel), for channel-group counts below / above one workgroup row (18, 288 > 256, 5, 3, 267)."""
+    N, H, W, C = cfg
+    torch.manual_seed(C + H)
+    x = torch.randn(N, H, W, C).to(dtype)
+    dy = torch.randn(N, H, W, C).to(dtype)
+    avg, _ = K.gap_fwd(x.to(dev), with_max=False)
+    ds = K.se_scale_bwd_ds(dy.to(dev), x.to(dev))
+    torch.cuda.synchronize()
+    ref_avg = x.double().mean(dim=(1, 2))
+    ref_ds = (x.double() * dy.double()).sum(dim=(1, 2))
+    assert float((avg.cpu().double() - ref_avg).abs().max()) < 1e-5 * max(1.0, float(ref_avg.abs().max())) + 1e-6
+    assert float((ds.cpu().double() - ref_ds).abs().max()) < 2e-5 * float(ref_ds.abs().max())

@@ -307,8 +307,9 @@ def test_mixed_frozen_and_train_mode_batchnorm_trains(dev):
     torch.manual_seed(0)
 
     def run(packed):
-        old = E.PACKED
+        old, old_t = E.PACKED, E.PACKED_TRAIN_BN
         E.PACKED = packed
+        E.PACKED_TRAIN_BN = False        # (the 3x3 route under batch statistics has its own test; here only the shortcut logic differs)
         try:
             m = _model("resnet50", dev).set_compute_dtype(torch.bfloat16)
             m.setmode("image")
@@ -321,7 +322,7 @@ def test_mixed_frozen_and_train_mode_batchnorm_trains(dev):
             torch.cuda.synchronize()
             return {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
         finally:
-            E.PACKED = old
+            E.PACKED, E.PACKED_TRAIN_BN = old, old_t
 
     got, ref = run(True), run(False)
     assert set(got) == set(ref) and "layer2.0.conv1.weight" in got

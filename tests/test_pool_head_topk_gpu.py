@@ -119,6 +119,34 @@ def test_linear_ce_mse(dev):
     assert abs(float(lw.cpu()) - 148.59375) < 1e-3
 
 
+@pytest.mark.parametrize("shape", [(64, 2304, 96), (64, 96, 2304), (50, 130, 70), (64, 40, 10), (17, 64, 2048)])
+@pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "silu"])
+def test_linear_tiled_products(shape, act, dev):
+    """The 64 x 64 LDS-tiled Linear kernels (forward, dx, dw/db; >= 1024 outputs -- the squeeze-excitation layers of EfficientNet
+    and the image heads at batch >= 16) against torch, every output activation of cs_linear_*, ragged tiles."""
+    M, N, Kf = shape
+    torch.manual_seed(M + N + Kf)
+    x = torch.randn(M, Kf, requires_grad=True)
+    w = (torch.randn(N, Kf) / Kf ** 0.5).requires_grad_()
+    b = torch.randn(N, requires_grad=True)
+    code = {"none": K.CS_ACT_NONE, "relu": K.CS_ACT_RELU, "sigmoid": K.CS_ACT_SIGMOID, "silu": K.CS_ACT_SILU}[act]
+    pre = F.linear(x, w, b)
+    y = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "silu": F.silu}[act](pre)
+    dy = torch.randn(M, N)
+    y.backward(dy)
+    xd, wd, bd = x.detach().to(dev), w.detach().to(dev), b.detach().to(dev)
+    yd, pred = K.linear_fwd(xd, wd, bd, code, want_preact=True)
+    saved = pred if act == "silu" else yd                   # cs_linear_bwd: the pre-activation for SiLU, the output otherwise
+    dx, dw, db = K.linear_bwd(xd, wd, dy.to(dev), saved, code)
+    torch.cuda.synchronize()
+    tol = 2e-5
+    assert float((yd.cpu() - y.detach()).abs().max()) < tol * max(1.0, float(y.detach().abs().max()))
+    assert float((pred.cpu() - pre.detach()).abs().max()) < tol * max(1.0, float(pre.detach().abs().max()))
+    assert float((dx.cpu() - x.grad).abs().max()) < tol * max(1.0, float(x.grad.abs().max()))
+    assert float((dw.cpu() - w.grad).abs().max()) < tol * max(1.0, float(w.grad.abs().max()))
+    assert float((db.cpu() - b.grad).abs().max()) < tol * max(1.0, float(b.grad.abs().max()))
+
+
 def _sample_reference(probs, groups, labels, tiles_per_pos, topk_neg):
     """inference.py:31-43 restated in numpy (the oracle for the selection kernel)."""
     groups = np.asarray(groups)

@@ -5,6 +5,7 @@
   c2s selection pass: eval fwd + softmax + adaptive top-k on 64-tile bags
   c4  EfficientNet-B3 tile classifier, bag 64, BN train                          (configs[3])
   c5  ResNet-50 encoder-decoder, batch 8 at 299x299, Dice, decoder training      (configs[4], per GPU)
+  c4g / c5g the c4 / c5 step replayed as one HIP graph
   c5x the same at 512x512, batch 4 (the reference's segmentation resolution, dataset/datasets.py MaskSet)
   c1cpu the c1 step on the host cores through the oracle (torch CPU fp32): the reference's own CPU-runnable case timed beside c1
 One JSON line per config: images-or-tiles per second and ms/step (inputs resident in HBM)."""
@@ -49,7 +50,7 @@ def tiles(n, size=299, seed=1234):
     return base.repeat((n + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:n].contiguous().to(dev)
 
 
-which = sys.argv[1:] or ["c1", "c2f", "c2s", "c4", "c5", "c5x", "c1cpu"]
+which = sys.argv[1:] or ["c1", "c2f", "c2s", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
@@ -130,6 +131,35 @@ if "c4" in which:
                                    "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None},
                       "algorithmic_mbytes_per_step": round(by / 3 / 1e6, 1), "ms_per_step": round(ms / 3, 3), "launches_per_step": len(recs) // 3}),
           flush=True)
+if "c4g" in which:
+    # the C4 step as ONE HIP graph (cellsegmentation_amd.graphed.GraphedStep): ~1900 launches per eager step keep the host as busy as the GPU
+    from cellsegmentation_amd.graphed import GraphedStep
+    m = fill(EN.MILefficientnetB3(num_classes=2)); m.setmode("tile"); m.set_encoder_grads(True); m.train()
+    x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
+    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, capturable=True, fused=FUSED)
+
+    def s4g_body(xb, yb):
+        optg.zero_grad(set_to_none=True)
+        loss = HF.cross_entropy(m(xb, freeze_bn=True), yb)
+        loss.backward()
+        optg.step()
+        return loss.detach()
+    g4 = GraphedStep(s4g_body, (x, y))
+    run("c4g efficientnet_b3 tile bag=64 bf16, the same step as one HIP graph", lambda: g4(x, y), 64, "tiles/s")
+if "c5g" in which:
+    from cellsegmentation_amd.graphed import GraphedStep
+    m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
+    x = tiles(8); mask = (torch.rand(8, 299, 299, device=dev) > 0.8).float()
+    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, capturable=True, fused=FUSED)
+
+    def s5g_body(xb, mb):
+        optg.zero_grad(set_to_none=True)
+        loss = HF.dice_loss(HF.softmax_channel(m(xb), 1), mb)
+        loss.backward()
+        optg.step()
+        return loss.detach()
+    g5 = GraphedStep(s5g_body, (x, mask))
+    run("c5g resnet50 segment B=8 299x299 bf16, the same step as one HIP graph", lambda: g5(x, mask), 8, "images/s")
 if "c5" in which:
     m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
     x = tiles(8); mask = (torch.rand(8, 299, 299, device=dev) > 0.8).float()
