@@ -69,6 +69,8 @@ _SIGNATURES = {
     "cs_colsum_partial_rows": (c_int, [c_longlong]),
     "cs_colsum_partial": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_positive_bits": (c_int, [_P, c_int, c_longlong, _P, _P]),
+    "cs_sample_sum_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "cs_sample_sum": (c_int, [_P, _P, c_int, c_float, _P, _P, c_int, c_int, c_int, _P]),
     "cs_maxpool3x3s2_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_gap_avgmax_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),

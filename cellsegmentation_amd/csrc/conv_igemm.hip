@@ -1778,6 +1778,224 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p, unsigned 
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient with SPECIALISED waves (round 3): a workgroup is 4 consumer waves (MFMA + transposing reads, the 2 x 2
+// layout of wgrad_dma_kernel) and 4 loader waves that do nothing but issue the LDS-DMA of the stages ahead.  Why: one 1-KiB DMA
+// piece costs the issuing wave ~100 cycles of instruction issue (MI355X_MICROARCH "LDS-DMA piece issue cost"), a stage of 32 pixels
+// is 4 pieces but only 8 MFMA (256 cycles) per wave -- in wgrad_dma_kernel every wave spends more time issuing its pieces than
+// multiplying, and an in-order wave cannot do both (450-650 TFLOP/s on the deep 1x1 layers).  Here the pieces are issued by other
+// waves, on the same SIMDs, while the consumers multiply; one s_barrier per stage hands a landed stage over and frees the oldest.
+//   loader   ks:  wait (own pieces of stage ks landed) | barrier | issue stage ks + D into the slot of stage ks - 1
+//   consumer ks:  barrier | multiply stage ks
+// ---------------------------------------------------------------------------------------------
+template <int BM, int NST, bool PLAIN, int BKP>
+__global__ __launch_bounds__(512) void wgrad_spec_kernel(WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int BN = 128;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_ROW_B = BM * 2, B_ROW_B = BN * 2;          // bytes per pixel row
+    constexpr int A_STAGE = BKP * A_ROW_B, B_STAGE = BKP * B_ROW_B;
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int A_RPI = 1024 / A_ROW_B, B_RPI = 1024 / B_ROW_B;     // rows per wave-instruction (4 or 8)
+    constexpr int A_I = BKP / A_RPI / 4, B_I = BKP / B_RPI / 4;       // instructions per wave per stage
+    static_assert(A_I >= 1 && B_I >= 1, "stage too small for 4 waves");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;                                // index inside the role
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const unsigned work = (blockIdx.x & 7) * (unsigned)p.per_xcd + (blockIdx.x >> 3);      // see wgrad_kernel
+    if ((blockIdx.x >> 3) >= (unsigned)p.per_xcd || work >= (unsigned)p.total_z * (unsigned)p.tiles) return;
+    const int z = (int)(work / (unsigned)p.tiles);
+    const int tile = (int)(work % (unsigned)p.tiles);
+    const int k0 = (tile % p.nkt) * BM;
+    const int q0 = (tile / p.nkt) * BN;
+    const int item = p.n_items ? z / p.nsplit : 0;
+    const int slice = p.n_items ? z % p.nsplit : z;
+    const long long mbeg = (long long)slice * p.m_per_split;
+    long long mend = mbeg + p.m_per_split;
+    if (mend > p.M) mend = p.M;
+
+    const void* xsel = p.x;
+    const void* gsel = p.dy;
+    float* dsel = p.dw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (p.n_items && item == i) { xsel = p.x_tab[i]; gsel = p.dy_tab[i]; dsel = p.dw_tab[i]; }
+    const i32x4 rsrc_x = dma_rsrc(xsel, x_bytes);
+    const i32x4 rsrc_g = dma_rsrc(gsel, dy_bytes);
+    const unsigned smem_base = lds_addr(smem_raw);
+
+    // ---- A (dy) lanes: row-in-instruction and logical channel chunk
+    constexpr int A_CPR = A_ROW_B / 16;                        // chunks per row (16 or 8)
+    const int a_rl = lane / A_CPR;                             // row inside one instruction
+    const int a_slot = lane % A_CPR;
+    const int a_swz = A_ROW_B == 256 ? ((a_rl & 3) << 2) : (((a_rl >> 1) & 1) << 2);
+    const int a_ch = k0 + (a_slot ^ a_swz) * 8;
+    const unsigned a_col = a_ch < p.KO ? (unsigned)a_ch * 2u : OOB;
+    const unsigned g_row_b = (unsigned)p.KO * 2u;
+    // ---- B (im2col of x) lanes
+    const int b_rl = lane >> 4;
+    const int b_slot = lane & 15;
+    const int bq = q0 + (b_slot ^ ((b_rl & 3) << 2)) * 8;
+    const bool b_ok = bq < p.QE;
+    int b_kh = 0, b_kw = 0, b_c = 0;
+    if (b_ok) {
+        const int tap = bq / p.Cq;
+        b_c = bq - tap * p.Cq;
+        b_kh = tap / p.S;
+        b_kw = tap - b_kh * p.S;
+    }
+    // Pixel walk.  The stage's first pixel (img0, oy0, ox0) is wave-uniform and advances in scalar registers; a lane's row is
+    // that pixel + a lane constant < 32, folded back into (img, oy, ox) with two multiply-high divisions (exact: the
+    // dividends stay below Q + 64 resp. P + 8) -- the per-row divergent carry loops of the register-staged kernel cost more
+    // issue cycles per K-step than its 8 MFMAs.  PLAIN (1x1, stride 1, no padding): source pixel == destination pixel.
+    const unsigned magicQ = 0xffffffffu / (unsigned)p.Q + 1u, magicP = 0xffffffffu / (unsigned)p.P + 1u;
+    unsigned img0, oy0, ox0;
+    {
+        const long long img = mbeg / ((long long)p.P * p.Q);
+        const int rem = (int)(mbeg - img * (long long)p.P * p.Q);
+        img0 = (unsigned)img;
+        oy0 = (unsigned)(rem / p.Q);
+        ox0 = (unsigned)(rem - (int)oy0 * p.Q);
+    }
+    unsigned mstep = (unsigned)mbeg;                          // M * KO * 2 < 2 GiB: 32-bit pixel arithmetic throughout
+    const unsigned mend32 = (unsigned)mend;
+    const unsigned x_row_b = (unsigned)p.C * 2u;
+    const unsigned b_col = (unsigned)b_c * 2u;
+    const int b_dy = b_kh - p.pad, b_dx = b_kw - p.pad_x;
+
+    auto issue = [&](int buf) {
+        const unsigned As = smem_base + (unsigned)buf * STAGE;
+        const unsigned Bs = As + A_STAGE;
+#pragma unroll
+        for (int i = 0; i < A_I; ++i) {
+            const int r = (wave * A_I + i) * A_RPI;            // first row of this instruction
+            const unsigned m = mstep + (unsigned)(r + a_rl);
+            const unsigned va = (m < mend32 && a_col != OOB) ? m * g_row_b + a_col : OOB;
+            dma16(rsrc_g, As + r * A_ROW_B, va);
+        }
+#pragma unroll
+        for (int i = 0; i < B_I; ++i) {
+            const int r = (wave * B_I + i) * B_RPI;
+            const unsigned m = mstep + (unsigned)(r + b_rl);
+            unsigned vb = OOB;
+            if constexpr (PLAIN) {
+                if (b_ok && m < mend32) vb = m * x_row_b + b_col;
+            } else {
+                const unsigned t = ox0 + (unsigned)(r + b_rl);
+                const unsigned w = __umulhi(t, magicQ);
+                const unsigned ox = t - w * (unsigned)p.Q;
+                const unsigned u = oy0 + w;
+                const unsigned w2 = __umulhi(u, magicP);
+                const unsigned oy = u - w2 * (unsigned)p.P;
+                const int iy = (int)oy * p.stride + b_dy;
+                const int ix = (int)ox * p.stride_x + b_dx;
+                if (b_ok && m < mend32 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    vb = (((img0 + w2) * (unsigned)p.H + (unsigned)iy) * (unsigned)p.W + (unsigned)ix) * x_row_b + b_col;
+            }
+            dma16(rsrc_x, Bs + r * B_ROW_B, vb);
+        }
+        mstep += BKP;
+        if constexpr (!PLAIN) {
+            ox0 += BKP;
+            const unsigned w = __umulhi(ox0, magicQ);
+            ox0 -= w * (unsigned)p.Q;
+            oy0 += w;
+            const unsigned w2 = __umulhi(oy0, magicP);
+            oy0 -= w2 * (unsigned)p.P;
+            img0 += w2;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing-read lane constants: per 16-lane group a 4(pixel) x 16(channel) block, lane i16 gets the 4 pixels of channel i16
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int qq = i16 >> 2, pp = i16 & 3;
+    // byte offset inside a row of this lane's 8-byte piece, swizzle included (row & 3 == qq: kr below is a multiple of 4)
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ch = wm * (BM / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
+        const int sw = A_ROW_B == 256 ? (qq << 2) : (((qq >> 1) & 1) << 2);
+        a_off[i] = (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = wn * (BN / 2) + j * 32 + 16 * (g16 & 1) + 4 * pp;
+        b_off[j] = (((ch >> 3) ^ (qq << 2)) << 4) + (ch & 7) * 2;
+    }
+
+    constexpr int D = NST - 1;                                 // stages in flight
+    constexpr int PER = A_I + B_I;                             // DMA instructions per loader wave per stage
+    const int nk = (int)((mend - mbeg + BKP - 1) / BKP);
+    if (loader) {
+#pragma unroll
+        for (int s0 = 0; s0 < D; ++s0)
+            if (s0 < nk) issue(s0);
+        for (int ks = 0; ks < nk; ++ks) {
+            // stage ks has landed once at most min(D-1, nk-1-ks) younger stages are outstanding (vmcnt retires in issue order)
+            const int younger = (nk - 1 - ks) < (D - 1) ? (nk - 1 - ks) : (D - 1);
+            if (younger >= 2 && D >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (younger == 1 && D >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dma_barrier();                                     // every loader's pieces of stage ks landed; the consumers are done with stage ks-1
+            if (ks + D < nk) issue((ks + D) % NST);
+        }
+        return;
+    }
+    for (int ks = 0; ks < nk; ++ks) {
+        dma_barrier();
+        const unsigned char* As = smem_raw + (size_t)(ks % NST) * STAGE;
+        const unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int s = 0; s < BKP / 16; ++s) {
+            union Frag { bf16x8 v; s16x4 q[2]; };
+            Frag a[TM], b[TN];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kr = 16 * s + 8 * hh + 4 * u + qq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(As + kr * A_ROW_B + a_off[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j].q[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + kr * B_ROW_B + b_off[j]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* slab = dsel + (long long)slice * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int qe = q0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = k0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ko < p.KO && qe < p.QE) slab[(long long)ko * p.QE + qe] = acc[i][j][r];
+            }
+        }
+}
+
 // number of split-K slices for KO x QE outputs over M pixels with a BM x 128 tile: ~512 workgroups (2 per CU);
 // every slice costs one extra write + read of the whole dW in fp32, so no more than needed to fill the chip
 int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
@@ -1823,6 +2041,20 @@ int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {
         if (plain) hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, true, BKP_>), grid, dim3(256), NST_ * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
         else hipLaunchKernelGGL((wgrad_dma_kernel<BM, NST_, false, BKP_>), grid, dim3(256), NST_ * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes); \
     } while (0)
+            // loader / consumer specialisation pays on the deep layers (tools/wgrad_ab.sh, 4 layers per launch: 256 -> 1024 @19x19 61 -> 52 us,
+            // 2048 -> 512 @10x10 65 -> 56, strided 512 -> 1024 139 -> 107, 1024 -> 512 110 -> 93) and on the pixel-paired stem (106 -> 85 us);
+            // the HBM-bound early layers (64 -> 256 @75x75: 146 vs 153 us) keep the four-wave kernel.  In the step: 1x1 family 1.113 -> 1.070 ms,
+            // stem 0.106 -> 0.085.  CELLSEG_WGRAD_SPEC = 1 forces the specialised kernel, 2 the four-wave one (A/B).
+            static const int spec_knob = cs_env_int_("CELLSEG_WGRAD_SPEC", 0);
+            const bool deep = BM == 128 && p.KO >= 256 && p.QE >= 256, stem = !plain && p.C <= 8;
+            if (spec_knob == 1 || (spec_knob == 0 && (deep || stem))) {
+                constexpr size_t stage_ = (size_t)32 * (BM + 128) * 2;
+                note_variant("wgrad_spec_kernel<%d,%d,%s,%d>", BM, 4, plain ? "true" : "false", 32);
+                if (plain) hipLaunchKernelGGL((wgrad_spec_kernel<BM, 4, true, 32>), grid, dim3(512), 4 * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes);
+                else hipLaunchKernelGGL((wgrad_spec_kernel<BM, 4, false, 32>), grid, dim3(512), 4 * stage_, st, p, (unsigned)x_bytes, (unsigned)g_bytes);
+                CS_LAUNCH_CHECK();
+                return CS_OK;
+            }
             if (g_wgrad_nst == 2) CS_WGRAD_DMA(2, 32);
             else if (g_wgrad_nst == 4) CS_WGRAD_DMA(4, 32);
             else if (g_wgrad_nst == 64) CS_WGRAD_DMA(2, 64);

@@ -114,9 +114,6 @@ extern "C" void cs_set_variant_(const char* name);
 int cs_wgrad2_splits_(const CsConvGeom* g, int dtype, int n_items);
 int cs_wgrad2_launch_(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab, float* const* dw_tab, int n_items,
                       void* stream);
-// dwse.hip: out[n][c] = scale * sum_p a[n][p][c] (* b[n][p][c] when b != NULL), NHWC rows, fp32 [N][C] output (overwritten).
-// The per-sample reduction of the squeeze-excitation blocks (average pool forward, ds = sum dy * x backward).
-int cs_sample_rowsum_(const void* a, const void* b, int dtype, float scale, float* out, int N, int HW, int C, void* stream);
 #define CS_CHECK_ARG(cond, msg)                         \
     do {                                                \
         if (!(cond)) {                                  \

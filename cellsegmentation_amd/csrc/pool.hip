@@ -276,10 +276,20 @@ extern "C" int cs_gap_avgmax_fwd(const void* x, int dtype, float* feat, int32_t*
     CS_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 8 == 0, "gap_fwd: bad extents");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((C / 8 + 63) / 64, N);
-    if (!with_max && HW >= 64) {
-        // plain average pool (squeeze-excitation): the row-strided per-sample reduction of dwse.hip
-        CS_CHECK_ARG(dtype == CS_F32 || dtype == CS_BF16, "gap_fwd: bad dtype");
-        return cs_sample_rowsum_(x, nullptr, dtype, 1.f / (float)HW, feat, N, HW, C, stream);
+    if (!with_max && HW >= 1024) {
+        int slabs = (HW + 511) / 512;
+        if (slabs > 64) slabs = 64;
+        const int slab = (HW + slabs - 1) / slabs;
+        if (hipMemsetAsync(feat, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) { cs_set_error_("gap_fwd: memset failed"); return CS_ERR_LAUNCH; }
+        dim3 g3((C / 8 + 63) / 64, N, (HW + slab - 1) / slab);
+        if (dtype == CS_F32)
+            hipLaunchKernelGGL(gap_avg_split_kernel<float>, g3, dim3(256), 0, st, (const float*)x, feat, HW, C, slab);
+        else if (dtype == CS_BF16)
+            hipLaunchKernelGGL(gap_avg_split_kernel<bf16_t>, g3, dim3(256), 0, st, (const bf16_t*)x, feat, HW, C, slab);
+        else
+            CS_CHECK_ARG(false, "gap_fwd: bad dtype");
+        CS_LAUNCH_CHECK();
+        return CS_OK;
     }
     if (dtype == CS_F32)
         hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, feat, argmax, HW, C, with_max);

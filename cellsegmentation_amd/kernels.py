@@ -715,12 +715,18 @@ def se_scale(x, s):
     return y
 
 
+def sample_sum(a, b=None, scale=1.0):
+    """fp32 [N, C]: scale * sum over the pixels of a (* b) per sample and channel (cs_sample_sum: row-strided, fixed-order fold)."""
+    N, H, W, C = a.shape
+    lib = _lib.load()
+    out = torch.empty((N, C), dtype=torch.float32, device=a.device)
+    ws = torch.empty((lib.cs_sample_sum_workspace(N, H * W, C) // 4,), dtype=torch.float32, device=a.device)
+    _lib.check(lib.cs_sample_sum(_p(a), _p(b), _code(a.dtype), float(scale), _p(out), _p(ws), N, H * W, C, _stream()), "sample_sum")
+    return out
+
+
 def se_scale_bwd_ds(dy, x):
-    N, H, W, C = x.shape
-    ds = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().cs_se_scale_bwd(_p(dy), _p(x), _code(x.dtype), None, None, _p(ds), None, N, H * W, C, 0, _stream()),
-               "se_scale_bwd(ds)")
-    return ds
+    return sample_sum(dy, x)
 
 
 def se_scale_bwd_dx(dy, s, davg):
@@ -759,6 +765,8 @@ def maxpool_bwd(dy, argmax, y_mask, in_hw):
 
 def gap_fwd(x, with_max=True):
     N, H, W, C = x.shape
+    if not with_max:
+        return sample_sum(x, None, 1.0 / (H * W)), None          # the squeeze-excitation average pool
     feat = torch.empty((N, C), dtype=torch.float32, device=x.device)
     am = torch.empty((N, C), dtype=torch.int32, device=x.device) if with_max else None
     _lib.check(_lib.load().cs_gap_avgmax_fwd(_p(x), _code(x.dtype), _p(feat), _p(am), N, H * W, C, 1 if with_max else 0, _stream()),

@@ -203,6 +203,14 @@ int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* st
 /* The same sums left as per-workgroup partial rows (layout and consumers as for cs_conv2d_dgrad's deferred column sums):
  * partial[b * 2*C + c], b < cs_colsum_partial_rows(M); no atomics, no zero-fill. */
 int cs_colsum_partial_rows(long long M);
+/* Per-sample, per-channel sums of an NHWC tensor [N][HW][C]: out[n][c] = scale * sum_p a[n][p][c] (* b[n][p][c] when b != NULL),
+ * fp32 [N][C], overwritten.  The two reductions of a squeeze-excitation block (torchvision SqueezeExcitation as used by
+ * model/efficientnet.py:83,107): the average pool (b = NULL, scale = 1/HW) and ds = sum dy * x of its backward.  Row-strided
+ * workgroups leave partial rows in `workspace` (cs_sample_sum_workspace bytes, caller-owned) that are added in a fixed order:
+ * bitwise reproducible, no atomics. */
+size_t cs_sample_sum_workspace(int N, int HW, int C);
+int cs_sample_sum(const void* a, const void* b, int dtype, float scale, float* out, float* workspace, int N, int HW, int C,
+                  void* stream);
 /* bit plane of a bf16 NHWC tensor: bits[i >> 3] bit (i & 7) = x[i] > 0 (the `mask_bits` operand of cs_conv2d_dgrad_packed for a
  * post-ReLU tensor that no convolution epilogue produced, e.g. torch.cat of two ReLU outputs, resnet.py:284-294); n_elems % 32 == 0 */
 int cs_positive_bits(const void* x, int dtype, long long n_elems, uint8_t* bits, void* stream);
