@@ -60,6 +60,7 @@ from cellsegmentation_amd import functional as HF  # noqa: E402
 from cellsegmentation_amd import kernels as K  # noqa: E402
 from cellsegmentation_amd import synth  # noqa: E402
 from cellsegmentation_amd.model import resnet as R  # noqa: E402
+from cellsegmentation_amd.optim import Adam  # noqa: E402
 from cellsegmentation_amd.parallel import GradReducer  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
@@ -349,6 +350,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the one-launch HIP Adam (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32 parity-mode side number (N=1, bf16 runs)")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
@@ -382,9 +384,10 @@ def main():
 
     model = build_model(dev, dtype)
     params = [p for p in model.parameters() if p.requires_grad]
-    # same torch.optim.Adam the reference constructs (train_tile.py:282); fused=True is torch's single-launch
-    # multi-tensor implementation of that update (the default foreach path is ~15 launches and 0.7 ms per step)
-    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4, fused=dev.type == "cuda")
+    # the Adam update the reference constructs (train_tile.py:282) as ONE HIP launch (cellsegmentation_amd.optim.Adam, csrc/optim.hip;
+    # tests/test_optim_gpu.py holds it to torch.optim.Adam step by step); --torch-adam: torch's own fused implementation (5 launches)
+    opt = (torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4, fused=True) if args.torch_adam
+           else Adam(params, lr=5e-4, weight_decay=1e-4))
     reducer = GradReducer(params).attach() if world > 1 else None       # buckets leave from inside the HIP backward
     if reducer is not None:
         reducer.broadcast_parameters(model)

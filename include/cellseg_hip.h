@@ -203,6 +203,19 @@ int cs_colsum(const void* g, int dtype, long long M, int C, float* out, void* st
 /* The same sums left as per-workgroup partial rows (layout and consumers as for cs_conv2d_dgrad's deferred column sums):
  * partial[b * 2*C + c], b < cs_colsum_partial_rows(M); no atomics, no zero-fill. */
 int cs_colsum_partial_rows(long long M);
+/* ---- optimizer ---------------------------------------------------------------------------------
+ * torch.optim.Adam's update (the optimizer the reference's drivers construct: train_tile.py:282, train_image.py:476,
+ * train_seg.py:309; L2 weight decay, no amsgrad) over up to cs_adam_max_tensors() fp32 tensors in one launch.
+ *   tensors_dev : DEVICE array of {p, m, v, n} for ALL tensors of the optimizer (built once)
+ *   grads_host  : HOST array of n_tensors device pointers, the gradients of tensors [t0, t0 + n_tensors) (passed by value)
+ *   chunks_dev  : DEVICE array of n_chunks (tensor index, first element / cs_adam_chunk_elems()) int pairs covering those tensors
+ *   step        : t >= 1 of this update; hyper-parameters as doubles (the bias corrections and 1 - beta are formed in double, as torch does) */
+typedef struct CsAdamTensor { float* p; float* m; float* v; long long n; } CsAdamTensor;
+int cs_adam_chunk_elems(void);
+int cs_adam_max_tensors(void);
+int cs_adam_step(const CsAdamTensor* tensors_dev, const void* const* grads_host, int t0, int n_tensors, const int* chunks_dev,
+                 int n_chunks, double lr, double beta1, double beta2, double eps, double weight_decay, double step, void* stream);
+
 /* Per-sample, per-channel sums of an NHWC tensor [N][HW][C]: out[n][c] = scale * sum_p a[n][p][c] (* b[n][p][c] when b != NULL),
  * fp32 [N][C], overwritten.  The two reductions of a squeeze-excitation block (torchvision SqueezeExcitation as used by
  * model/efficientnet.py:83,107): the average pool (b = NULL, scale = 1/HW) and ds = sum dy * x of its backward.  Row-strided

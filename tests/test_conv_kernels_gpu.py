@@ -276,3 +276,19 @@ def test_wgrad_finalize_batched_matches_torch(K_, Cin, R, Cp, nsplit, n, dev):
     for i in range(n):
         raw = slabs[i].double().sum(0)[..., :Cin].permute(0, 3, 1, 2)
         assert float((dws2[i].cpu().double() - raw).abs().max()) < 2e-5 * (1 + nsplit ** 0.5) * float(raw.abs().max())
+
+
+def test_wave_specialised_weight_gradient_on_every_shape(dev):
+    """wgrad_spec_kernel (4 loader + 4 consumer waves) is selected by rule for the deep layers only; CELLSEG_WGRAD_SPEC=1 forces it for
+    every LDS-DMA weight gradient, =2 forces the four-wave kernel.  Both extremes must pass this file's parity tests and the exact
+    integer-data test of the packed kernels' file (the knob is read once per process: child interpreters)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("1", "2"):
+        env = dict(os.environ, CELLSEG_WGRAD_SPEC=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_kernels_gpu.py"),
+                            os.path.join(root, "tests", "test_conv_packed_gpu.py"), "-m", "gpu", "-x", "-q",
+                            "-k", "not wave_specialised"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+        assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])

@@ -1,0 +1,72 @@
+"""cellsegmentation_amd.optim.Adam (one HIP launch, csrc/optim.hip) against torch.optim.Adam on the same parameters and gradients:
+the optimizer the reference's drivers construct (train_tile.py:282: lr 5e-4, weight_decay 1e-4)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cellsegmentation_amd import optim as O  # noqa: E402
+
+
+def _params(dev, shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(s, generator=g).to(dev).requires_grad_() for s in shapes]
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-4])
+def test_adam_matches_torch_over_several_steps(wd, dev):
+    shapes = [(64, 3, 7, 7), (64,), (256, 64, 1, 1), (512, 512, 3, 3), (2, 2048), (2,), (17,), (1000003,)] + [(33, 5)] * 400   # > 320 tensors
+    ours, ref = _params(dev, shapes, 1), _params(dev, shapes, 1)
+    a = O.Adam(ours, lr=5e-4, weight_decay=wd)
+    b = torch.optim.Adam(ref, lr=5e-4, weight_decay=wd)
+    g = torch.Generator().manual_seed(7)
+    for step in range(5):
+        for p, q in zip(ours, ref):
+            gr = torch.randn(p.shape, generator=g).to(dev)
+            p.grad, q.grad = gr, gr.clone()
+        if step == 3:
+            a.param_groups[0]["lr"] = b.param_groups[0]["lr"] = 1e-3          # what a scheduler does
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ours, ref):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 5.0
+        assert float((sa["state"][k]["exp_avg_sq"] - sb["state"][k]["exp_avg_sq"]).abs().max()) <= 1e-6 * float(sb["state"][k]["exp_avg_sq"].abs().max())
+    # state interchange: torch's state into ours, one more identical step
+    a2 = O.Adam(ours, lr=5e-4, weight_decay=wd)
+    import copy
+    a2.load_state_dict(copy.deepcopy(b.state_dict()))       # (load_state_dict may alias same-device tensors: the two optimizers must not share moments)
+    for p, q in zip(ours, ref):
+        gr = torch.ones_like(p)
+        p.grad, q.grad = gr, gr.clone()
+    a2.step()
+    b.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ours, ref):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
+
+
+def test_adam_skips_parameters_without_gradients_and_unaligned_views(dev):
+    flat = torch.randn(4099, device=dev)
+    p1 = flat[3:1030].detach().clone().requires_grad_()                      # fresh storage, aligned
+    base = torch.randn(5000, device=dev)
+    p2 = base[1:4098].detach().requires_grad_()                              # 4-byte-aligned view: the scalar path of the kernel
+    p3 = torch.randn(10, device=dev, requires_grad=True)                     # never gets a gradient
+    q1, q2 = p1.detach().clone().requires_grad_(), p2.detach().clone().requires_grad_()
+    a = O.Adam([p1, p2, p3], lr=1e-2)
+    b = torch.optim.Adam([q1, q2], lr=1e-2)
+    for _ in range(3):
+        for p, q in ((p1, q1), (p2, q2)):
+            p.grad = torch.sin(p.detach() * 3)
+            q.grad = p.grad.clone()
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    assert float((p1 - q1).abs().max()) < 2e-6 and float((p2 - q2).abs().max()) < 2e-6
+    assert len(a.state[p3]) == 0
+    with pytest.raises(ValueError):
+        O.Adam([p1], amsgrad=True)

@@ -23,7 +23,15 @@ from cellsegmentation_amd.model import efficientnet as EN, resnet as R  # noqa: 
 
 dev = torch.device("cuda:0")
 STEPS, WARM = int(os.environ.get("STEPS", "10")), 3
-FUSED = os.environ.get("FUSED_ADAM", "1") != "0"      # torch's single-launch implementation of the same Adam update (as bench.py)
+FUSED = os.environ.get("FUSED_ADAM", "1") != "0"      # graphed configs: torch's fused implementation (capturable) of the Adam update
+HIP_ADAM = os.environ.get("HIP_ADAM", "1") != "0"     # eager configs: cellsegmentation_amd.optim.Adam (one launch), as bench.py
+
+
+def make_adam(params, lr, wd):
+    if HIP_ADAM:
+        from cellsegmentation_amd.optim import Adam
+        return Adam(params, lr=lr, weight_decay=wd)
+    return torch.optim.Adam(params, lr=lr, weight_decay=wd, fused=FUSED)
 
 
 def fill(m):
@@ -54,7 +62,7 @@ which = sys.argv[1:] or ["c1", "c2f", "c2s", "c4", "c4g", "c5", "c5g", "c5x", "c
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=8e-5, weight_decay=1e-4)
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 8e-5, 1e-4)
 
     def s1():
         opt.zero_grad(set_to_none=True)
@@ -80,7 +88,7 @@ if "c1" in which:
 if "c2f" in which:
     m = fill(R.MILresnet50()); m.setmode("tile"); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, fused=FUSED)
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
 
     def s2():
         opt.zero_grad(set_to_none=True)
@@ -100,7 +108,7 @@ if "c2s" in which:
 if "c4" in which:
     m = fill(EN.MILefficientnetB3(num_classes=2)); m.setmode("tile"); m.set_encoder_grads(True); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, fused=FUSED)
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
 
     def s4():
         opt.zero_grad(set_to_none=True)
@@ -163,7 +171,7 @@ if "c5g" in which:
 if "c5" in which:
     m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
     x = tiles(8); mask = (torch.rand(8, 299, 299, device=dev) > 0.8).float()
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, fused=FUSED)
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
 
     def s5():
         opt.zero_grad(set_to_none=True)
@@ -173,7 +181,7 @@ if "c5" in which:
 if "c5x" in which:
     m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
     x = tiles(4, 512); mask = (torch.rand(4, 512, 512, device=dev) > 0.8).float()
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, fused=FUSED)
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
 
     def s5x():
         opt.zero_grad(set_to_none=True)
