@@ -115,7 +115,7 @@ def kernel_name(kind, g, dtype):
 def _traffic_for(name, by_per_launch):
     """HBM bytes per launch from the committed PMC passes (tools/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs,
     gfx950-corrected), newest round first; None when the kernel was not sampled."""
-    for fn in ("round2_traffic.json", "round1_traffic.json"):
+    for fn in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(tpath):
             continue

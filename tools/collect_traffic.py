@@ -32,17 +32,19 @@ def per_kernel(path, counter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    every = len(sys.argv) > 4 and sys.argv[4] == "all"          # other configs (EfficientNet, segmentation): every kernel of the step
+    what = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 3 --warmup 1"
     f, fn = per_kernel(fetch_dir, "FETCH_SIZE")
     w, _ = per_kernel(write_dir, "WRITE_SIZE")
     res = {}
     for k in f:
-        if not k.startswith(("igemm", "wgrad", "conv2_")):
+        if not every and not k.startswith(("igemm", "wgrad", "conv2_")):
             continue
         rd = f[k] * 1024 * 2.0          # gfx950: FETCH_SIZE = 1/2 of a wide coalesced read
         wr = w.get(k, 0.0) * 1024
         res[k] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "hbm_bytes_per_launch": round(rd + wr),
                   "launches_sampled": fn[k], "fetch_size_kib_raw": round(f[k], 1), "write_size_kib_raw": round(w.get(k, 0.0), 1)}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over " + what,
                "correction": "read side x2 (gfx950 FETCH_SIZE half-count for 16 B/lane streams); KiB -> bytes", "kernels": res}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1)[:1500])
 
