@@ -44,6 +44,9 @@ struct C2Params {
     int SH, SW, SC, NS;
     int DH, DW, NOUT;
     int Wp, Hp, PW, PH;            // padded-linear geometry of the source: Wp = SW + PW, Hp = SH + PH
+    int LW;                        // LDS rows between two filter rows: Wp (linear pixel runs) or TW + S - 1 (2-D tiles)
+    int TH, TWl, tiles_x, tiles_y; // 2-D tiles (wide images): TH x (1 << TWl) destination pixels, tiles per image
+    unsigned n_tiles;              // 2-D: NS * tiles_y * tiles_x
     int stride;                    // 1x1 kernel only
     int gather, GH, GWp;           // ring forward of the pixel-paired stem (cs_stem_fwd_packed): LDS row = 32 gathered 16-byte (kh, pair) slots
     int add_stride, AH, AW;        // ring data gradient: the add operand is a COMPACT [NS][AH][AW][NOUT] tensor that only exists at destination
@@ -309,6 +312,7 @@ __device__ __forceinline__ unsigned nz_bits8(const uint4& o) {
 // Row-arrangement offsets of one pixel tile, computed ONCE per tile: the byte offset of (32-pixel tile i, half q) is rb + (2i+q) * 16
 // rows, valid while its row index stays below M -- 3 instructions per access instead of a multiply-add chain per (i, q).
 struct TileOffs {
+    static constexpr bool kPreset = false;
     static constexpr unsigned NONE = 0x7fffff00u;      // M < 2^31 - 512: NONE + 16 * 7 neither wraps nor passes the test
     unsigned rb, mr, bb, br;
     // `piece`: which 16 bytes of the wave's 64 this lane handles; bits: lanes with (lane & 3) == q hold the dword of pixel q
@@ -330,6 +334,32 @@ struct TileOffs {
         return br + 32u * (unsigned)i < M ? bb + (unsigned)i * (4u * nout) : OOB;
     }
 };
+// The same offsets for a 2-D pixel tile (wide images, round 3): local pixel j of the tile is (y0 + (j >> TWl), x0 + (j & (TW - 1))); every
+// (32-pixel tile, half) has its own offset, computed once before the main loop (3 * TM registers instead of 4).
+template <int TM> struct TileOffs2D {
+    static constexpr bool kPreset = true;
+    unsigned ro[TM][2], bo[TM];
+    __device__ __forceinline__ void set2d(unsigned n, unsigned y0, unsigned x0, unsigned dh, unsigned dw, unsigned twl, unsigned j0, bool alive,
+                                          unsigned nout, unsigned n_w, unsigned piece) {
+        const unsigned lane = threadIdx.x & 63, tw1 = (1u << twl) - 1u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned j = j0 + 32u * i + 16u * q + (lane >> 2);
+                const unsigned y = y0 + (j >> twl), x = x0 + (j & tw1);
+                const unsigned m = (n * dh + y) * dw + x;
+                ro[i][q] = (alive && y < dh && x < dw) ? (m * nout + n_w + 8u * piece) * 2u : OOB;
+            }
+            const unsigned jb = j0 + 32u * i + (lane >> 2) + 16u * (lane & 1u);
+            const unsigned yb = y0 + (jb >> twl), xb = x0 + (jb & tw1);
+            const unsigned mb = (n * dh + yb) * dw + xb;
+            bo[i] = (alive && !(lane & 2u) && yb < dh && xb < dw) ? (mb * nout + n_w) >> 3 : OOB;
+        }
+    }
+    __device__ __forceinline__ unsigned row(unsigned, unsigned, int i, int q) const { return ro[i][q]; }
+    __device__ __forceinline__ unsigned bit(unsigned, unsigned, int i) const { return bo[i]; }
+};
 // the 16 bytes with element k kept where bit k of b is set
 __device__ __forceinline__ uint4 keep_bits8(const uint4& o, unsigned b) {
     unsigned wds[4] = {o.x, o.y, o.z, o.w};
@@ -341,7 +371,7 @@ __device__ __forceinline__ uint4 keep_bits8(const uint4& o, unsigned b) {
     return make_uint4(wds[0], wds[1], wds[2], wds[3]);
 }
 
-template <int TM, bool PRE_RES, bool DG> struct Epilogue {
+template <int TM, bool PRE_RES, bool DG, typename TO = TileOffs> struct Epilogue {
     const C2Params& p;
     unsigned m0w, slab_row;
     int n_w;
@@ -364,7 +394,7 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
     __device__ __forceinline__ Epilogue(const C2Params& p_, unsigned m0w_, int n_w_, unsigned slab_row_, bool alive_, unsigned scr_)
         : p(p_), m0w(m0w_), slab_row(slab_row_), n_w(n_w_), alive(alive_), scr(scr_) {}
 
-    TileOffs to;               // row arrangement: lane -> (pixel 16q + (lane >> 2) of tile i, piece lane & 3)
+    TO to;                     // row arrangement: lane -> (pixel 16q + (lane >> 2) of tile i, piece lane & 3)
     __device__ __forceinline__ unsigned row_lds(int q) const {       // row arrangement: the lane's slot in the scratch
         const int lane = threadIdx.x & 63;
         return scr + (unsigned)(16 * q + (lane >> 2)) * EPI_ROW + (unsigned)(lane & 3) * 16u;
@@ -378,7 +408,7 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
         const int lane = threadIdx.x & 63;
         const int hh = lane >> 5;
         const unsigned out_bytes = p.M * (unsigned)p.NOUT * 2u;
-        to.set(m0w, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
+        if constexpr (!TO::kPreset) to.set(m0w, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
         r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
         r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, p.residual ? out_bytes : 0u, 0x00020000);
         r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.bits_in), 0, p.bits_in ? out_bytes >> 4 : 0u, 0x00020000);
@@ -457,7 +487,9 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s1[k] = 0.f;
             }
-            if (p.slab) {                      // statistics are those of the STORED values; rows past the end are zeros
+            if (p.slab) {                      // statistics are those of the STORED values; rows that are not stored count as zeros
+                if (to.row(p.M, (unsigned)p.NOUT, I, 0) == OOB) o0 = make_uint4(0u, 0u, 0u, 0u);
+                if (to.row(p.M, (unsigned)p.NOUT, I, 1) == OOB) o1 = make_uint4(0u, 0u, 0u, 0u);
                 const unsigned ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -503,7 +535,11 @@ template <int TM, bool PRE_RES, bool DG> struct Epilogue {
 // Halo kernel: R x S taps (NTAP = R*S, a multiple of 3; S = SK), stride 1.  Workgroup = 4 waves as WM x WN;
 // wave tile = (32*TM pixels) x 32 channels; NBW = 16-row LDS blocks each wave fetches per 64-channel chunk.
 // =================================================================================================
-template <int NTAP, int SK, int TM, int WM, int WN, int NBW, bool DG>
+// T2D (round 3): the pixel tile is TH x TW destination pixels of ONE image instead of a run of consecutive pixels.  A run's window is
+// BM + 2 * Wp + 2 rows (+ Wp more where it crosses into the next image): 2.2x the tile at 75 x 75, 5.8x at 150 x 150 -- the decoder's two
+// widest layers (resnet.py:162-163) did not fit two stages.  An 8 x 16 tile's window is 10 x 18 = 180 rows for 128 pixels at any image
+// width; LDS row of window position (ly, lx) = ly * LW + lx, LW = TW + S - 1, so a tap is still a constant row shift.
+template <int NTAP, int SK, int TM, int WM, int WN, int NBW, bool DG, bool T2D = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void conv2_halo_kernel(C2Params p) {
     static_assert(WM * WN == 4 && NTAP % 3 == 0 && NBW <= 8, "layout");
     constexpr int BM = WM * TM * 32, BN = WN * 32;
@@ -527,39 +563,67 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     const unsigned slot = bid >> 3;
     const unsigned mtile = (slot / (unsigned)p.n_ntiles) * 8u + (bid & 7u);
     const unsigned m0 = mtile * BM;
-    if (m0 >= p.M) return;
+    if (T2D ? mtile >= p.n_tiles : m0 >= p.M) return;
     const int n0 = (int)(slot % (unsigned)p.n_ntiles) * BN;
     const int n_w = n0 + wn * 32;
     const bool alive = n_w < p.NOUT;
 
-    auto pos0 = [&](unsigned m) -> unsigned {      // padded-linear position of tap offset (0,0) of destination pixel m
-        const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
-        const unsigned x = m - yall * (unsigned)p.DW;
-        const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
-        const unsigned y = yall - n * (unsigned)p.DH;
-        return (n * (unsigned)p.Hp + y) * (unsigned)p.Wp + x;
-    };
-    const unsigned Lmin = pos0(m0);
-    const unsigned m0w = m0 + (unsigned)(wm * TM * 32);
+    using TOffs = std::conditional_t<T2D, TileOffs2D<TM>, TileOffs>;
+    Epilogue<TM, (NBW == 8), DG, TOffs> epi(p, m0 + (unsigned)(wm * TM * 32), n_w, mtile * WM + wm, alive, 0u);
     unsigned qb[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        unsigned m = m0w + 32u * i + (unsigned)l31;
-        if (m > p.M - 1) m = p.M - 1;
-        qb[i] = pos0(m) - Lmin;
-    }
-    // this wave's LDS blocks: b = wave + 4j; lane -> (row 16b + (lane & 15), chunk column lane >> 4 (+4 for the second piece))
     unsigned voff[NBW];
+    if constexpr (T2D) {
+        const unsigned per_img = (unsigned)(p.tiles_y * p.tiles_x);
+        const unsigned n = mtile / per_img, tr = mtile - n * per_img;
+        const unsigned ty = tr / (unsigned)p.tiles_x, tx = tr - ty * (unsigned)p.tiles_x;
+        const unsigned y0 = ty * (unsigned)p.TH, x0 = tx << p.TWl;
+        const unsigned j0 = (unsigned)(wm * TM * 32);
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const unsigned L = Lmin + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
-        const unsigned row = udivm(L, p.mg_wp, p.sh_wp);
-        const unsigned col = L - row * (unsigned)p.Wp;
-        const unsigned n = udivm(row, p.mg_hp, p.sh_hp);
-        const unsigned ry = row - n * (unsigned)p.Hp;
-        const bool real = col >= (unsigned)p.PW && ry >= (unsigned)p.PH && n < (unsigned)p.NS;
-        const unsigned pix = (n * (unsigned)p.SH + (ry - (unsigned)p.PH)) * (unsigned)p.SW + (col - (unsigned)p.PW);
-        voff[j] = real ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+        for (int i = 0; i < TM; ++i) {
+            const unsigned j = j0 + 32u * i + (unsigned)l31;
+            qb[i] = (j >> p.TWl) * (unsigned)p.LW + (j & ((1u << p.TWl) - 1u));
+        }
+        // this wave's LDS blocks: b = wave + 4j; lane -> window position 16b + (lane & 15) = (ly, lx), source pixel (y0 - PH + ly, x0 - PW + lx)
+        const unsigned win_rows = (unsigned)(p.TH + (NTAP / SK) - 1) * (unsigned)p.LW;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const unsigned l = 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+            const unsigned ly = udivm(l, p.mg_wp, p.sh_wp);                  // / LW
+            const unsigned lx = l - ly * (unsigned)p.LW;
+            const int sy = (int)(y0 + ly) - p.PH, sx = (int)(x0 + lx) - p.PW;
+            const bool real = l < win_rows && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
+            const unsigned pix = (n * (unsigned)p.SH + (unsigned)sy) * (unsigned)p.SW + (unsigned)sx;
+            voff[j] = real ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+        }
+        epi.to.set2d(n, y0, x0, (unsigned)p.DH, (unsigned)p.DW, (unsigned)p.TWl, j0, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
+    } else {
+        auto pos0 = [&](unsigned m) -> unsigned {      // padded-linear position of tap offset (0,0) of destination pixel m
+            const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+            const unsigned x = m - yall * (unsigned)p.DW;
+            const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+            const unsigned y = yall - n * (unsigned)p.DH;
+            return (n * (unsigned)p.Hp + y) * (unsigned)p.Wp + x;
+        };
+        const unsigned Lmin = pos0(m0);
+        const unsigned m0w = m0 + (unsigned)(wm * TM * 32);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            unsigned m = m0w + 32u * i + (unsigned)l31;
+            if (m > p.M - 1) m = p.M - 1;
+            qb[i] = pos0(m) - Lmin;
+        }
+        // this wave's LDS blocks: b = wave + 4j; lane -> (row 16b + (lane & 15), chunk column lane >> 4 (+4 for the second piece))
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const unsigned L = Lmin + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+            const unsigned row = udivm(L, p.mg_wp, p.sh_wp);
+            const unsigned col = L - row * (unsigned)p.Wp;
+            const unsigned n = udivm(row, p.mg_hp, p.sh_hp);
+            const unsigned ry = row - n * (unsigned)p.Hp;
+            const bool real = col >= (unsigned)p.PW && ry >= (unsigned)p.PH && n < (unsigned)p.NS;
+            const unsigned pix = (n * (unsigned)p.SH + (ry - (unsigned)p.PH)) * (unsigned)p.SW + (col - (unsigned)p.PW);
+            voff[j] = real ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+        }
     }
     const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
     const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
@@ -568,7 +632,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
     const unsigned smem_base = lds_off(smem);
 
     static_assert(TM >= 2 && TM <= 4, "the register map of the main loop holds up to 4 pixel tiles per wave");
-    Epilogue<TM, (NBW > 5), DG> epi(p, m0w, n_w, mtile * WM + wm, alive, 0u);
     epi.prefetch();
     CS_STAMP(4);
     own_registers();
@@ -592,9 +655,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
         constexpr int CUR = T % 3, NX2 = (T + 2) % 3;
         constexpr bool has1 = HN || (T + 1 < NTAP);
         constexpr bool has2 = HN || (T + 2 < NTAP);
-        constexpr int D0 = (HN && T < NBW) ? 2 : 0;
-        constexpr int D1 = (HN && T >= 1 && T - 1 < NBW) ? 2 : 0;
-        constexpr int D2 = (HN && T >= 2 && T - 2 < NBW) ? 2 : 0;
+        // (the last tap of a chunk leaves none of the next chunk's pieces in flight: the barrier that follows hands the stage over.
+        // With NBW <= 5 the last piece is issued at tap 4 and the terms vanish by themselves; NBW = 7 issues its last piece at tap 6.)
+        constexpr bool LAST = T == NTAP - 1;
+        constexpr int D0 = (HN && !LAST && T < NBW) ? 2 : 0;
+        constexpr int D1 = (HN && !LAST && T >= 1 && T - 1 < NBW) ? 2 : 0;
+        constexpr int D2 = (HN && !LAST && T >= 2 && T - 2 < NBW) ? 2 : 0;
         constexpr unsigned CUR_STAGE = ODD ? STAGE : 0u, NXT_STAGE = ODD ? 0u : STAGE;
         if constexpr (has2) {
             bload4<NX2>(rsrc_b, bvoff, wsoff);
@@ -602,8 +668,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
         }
         if constexpr (D0) dma_block(rsrc_a, smem_base + NXT_STAGE + (unsigned)(wave + 4 * T) * 2048u, voff[T < NBW ? T : 0], nxt_soff);
         wait_vm<(has1 ? 4 : 0) + (has2 ? 4 : 0) + D0 + D1 + D2>();
-        const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.Wp + (unsigned)(T % SK);
-        const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.Wp + (unsigned)((T + 1) % SK);
+        const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.LW + (unsigned)(T % SK);
+        const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.LW + (unsigned)((T + 1) % SK);
         // the epilogue's exchange scratch: the stage nobody reads or fills during the last chunk (single-stage launches: the
         // bytes behind the stage)
         if constexpr (T == NTAP - 1 && !HN) epi.scr = smem_base + NXT_STAGE + (unsigned)wave * EPI_WAVE;
@@ -614,7 +680,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
         [&]<int... Ts>(std::integer_sequence<int, Ts...>) { (tap.template operator()<Ts, ODD, HN>(), ...); }(std::make_integer_sequence<int, NTAP>{});
     };
 
-    if constexpr (NBW > 5) {
+    if constexpr (NBW == 8) {
         chunk.template operator()<false, false>();         // single-chunk launches only (one 64 KiB stage)
     } else {
         for (int cc = 0; cc < p.NCC; cc += 2) {
@@ -977,6 +1043,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(48))) void c
     // prologue = steps -2 and -1 of the schedule
     issue_b.template operator()<0>(); issue_a(); advance_fetch();
     issue_b.template operator()<1>(); issue_a(); advance_fetch();
+    // (Round 3, second experiment: a 512-thread variant with four LOADER waves issuing the operand-row DMA five steps ahead over a
+    // six-slot ring (one workgroup per compute unit), the consumers waiting for their own weight loads only -- vmcnt retires in order
+    // per wave, so a wave that also streams weights cannot keep more than two steps of rows in flight.  Correct on all 52 packed
+    // tests, and slower or equal everywhere: 1024 -> 256 @19x19 26.0 -> 29.9 us, 2048 -> 512 @10x10 (one workgroup per compute unit
+    // either way) 25.9 -> 26.4 us.  PMC on that launch: per 64-deep step a consumer wave is parked ~660 cycles (barrier, first LDS
+    // fragment, weight wait), issues for ~590 and sits behind its own MFMAs for ~590 (512 cycles of MFMA busy): the rows were never
+    // what it waited for.  Removed; profiles/round3_notes.md.)
     // (Round 3 tried issuing the loads of step s+2 BETWEEN the MFMAs of step s instead of in front of them -- B0 A0 B1 A1 B2 B3 after
     // MFMA 0..5, vmcnt(8 + ...) -- to take the ~1000 cycles of issue that round 2's stamps showed off the critical path of the deep
     // contractions.  All tests passed and nothing moved: 2048 -> 512 @10x10 26.4 vs 26.0 us, 1024 -> 256 @19x19 28.5 vs 28.6 us.  The
@@ -1091,6 +1164,7 @@ void magic(unsigned d, unsigned& mg, unsigned& sh) {
 struct C2Plan {
     int cfg, nbw, ncc, rows;       // rows = partial column-sum rows
     int tm;                        // pixel tiles (32 px) per wave: 1 x 4 configuration only
+    int t2d;                       // halo kernel on 8 x 16-pixel tiles (wide images)
     C2Params p;
 };
 
@@ -1142,6 +1216,9 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
         const int nb = (window_blocks(256) + 3) / 4;
         if (nb <= 8) { cfg = 2; nbw = 8; }
     }
+    // wide images: 8 x 16-pixel tiles (see conv2_halo_kernel T2D); 1 x 4 waves of 4 pixel tiles, 180 window rows = 3 blocks per wave
+    int t2d = 0;
+    if (!cfg && NOUT % 128 == 0 && (8 + g->R - 1) * (16 + g->S - 1) <= 192) { cfg = 1; nbw = 3; tm = 4; t2d = 1; }
     if (!cfg) return false;
     if (cfg == 1 && ncc == 1 && nbw > 5) nbw = 8;
     C2Params& p = pl.p;
@@ -1150,10 +1227,18 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     p.DH = DH; p.DW = DW; p.NOUT = NOUT;
     p.Wp = Wp; p.Hp = Hp; p.PW = PWH; p.PH = PWH;
     p.stride = 1;
+    p.LW = t2d ? 16 + g->S - 1 : Wp;
     magic((unsigned)DW, p.mg_dw, p.sh_dw);
     magic((unsigned)DH, p.mg_dh, p.sh_dh);
-    magic((unsigned)Wp, p.mg_wp, p.sh_wp);
+    magic((unsigned)p.LW, p.mg_wp, p.sh_wp);
     magic((unsigned)Hp, p.mg_hp, p.sh_hp);
+    if (t2d) {
+        p.TH = 8; p.TWl = 4;
+        p.tiles_x = cs_ceil_div(DW, 16); p.tiles_y = cs_ceil_div(DH, 8);
+        const long long nt = (long long)g->N * p.tiles_x * p.tiles_y;
+        if (nt >= (1ll << 28)) return false;
+        p.n_tiles = (unsigned)nt;
+    }
     p.NCC = ncc;
     p.M = (unsigned)M;
     p.src_bytes = (unsigned)src_bytes;
@@ -1164,7 +1249,8 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     const int BM = cfg == 1 ? 32 * tm : 256, BN = cfg == 1 ? 128 : 64;
     p.n_ntiles = cs_ceil_div(NOUT, BN);
     pl.cfg = cfg; pl.nbw = nbw; pl.ncc = ncc; pl.tm = cfg == 1 ? tm : 4;
-    pl.rows = cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
+    pl.t2d = t2d;
+    pl.rows = t2d ? (int)p.n_tiles : cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
     return true;
 }
 // group count of a ring launch (a multiple of 8: one group per XCD slot): minimises rounds-of-residency x pixel tiles per workgroup;
@@ -1249,7 +1335,7 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
 
 // dynamic LDS beyond 64 KiB has to be allowed per (device, kernel): cs_api.cpp keeps the table
 template <typename F> bool allow_lds(F fn, size_t bytes) {
-    return cs_allow_dynamic_lds_(reinterpret_cast<const void*>(fn), bytes, 81920) != 0;
+    return cs_allow_dynamic_lds_(reinterpret_cast<const void*>(fn), bytes, bytes > 81920 ? 163840 : 81920) != 0;
 }
 
 template <int TM, int WM, int WN, bool DG>
@@ -1292,16 +1378,16 @@ int launch_gemm(const C2Plan& pl, hipStream_t st) {
     return launch_ring_t<2, 2, 2, DG>(p, st);
 }
 
-template <int TM, int NBW, bool DG>
+template <int TM, int NBW, bool DG, bool T2D = false>
 int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
-    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 32 * TM);
+    const unsigned n_mt = T2D ? p.n_tiles : (unsigned)cs_ceil_div(p.M, 32 * TM);
     dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
     // two stages: the epilogue borrows the idle one; one stage: its exchange scratch sits behind it
     const size_t lds = two_stage ? (size_t)NBW * 8192 * 2 : (size_t)NBW * 8192 + EPI_LDS;
-    auto fn = conv2_halo_kernel<9, 3, TM, 1, 4, NBW, DG>;
+    auto fn = conv2_halo_kernel<9, 3, TM, 1, 4, NBW, DG, T2D>;
     if (!allow_lds(fn, lds)) return CS_ERR_LAUNCH;
     char name[64];
-    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,%d,1,4,%d,%s>", TM, NBW, DG ? "true" : "false");
+    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,%d,1,4,%d,%s%s>", TM, NBW, DG ? "true" : "false", T2D ? ",true" : "");
     cs_set_variant_(name);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
@@ -1321,6 +1407,7 @@ int launch_halo(const C2Plan& pl, hipStream_t st) {
         return CS_OK;
     }
     const int two = pl.ncc > 1;
+    if (pl.t2d) return launch_cfg1<4, 3, DG, true>(p, st, two);
 #define CS_HALO_TM(TM_)                                         \
     switch (pl.nbw) {                                           \
         case 3: return launch_cfg1<TM_, 3, DG>(p, st, two);     \

@@ -231,6 +231,7 @@ bool plan(const CsConvGeom* g, int dtype, int n_items, W2Plan& pl) {
     else if (Wp <= 23) { bl = 128; xr = 176; }
     else if (Wp <= 39) { bl = 64; xr = 144; }
     else if (Wp <= 79) { bl = 64; xr = 224; }
+    else if (Wp <= 159) { bl = 64; xr = 384; }       // the 150 x 150 (and 128 x 128) decoder layers: 112 KiB of LDS, one workgroup per compute unit
     else return false;
     const unsigned long long D = (unsigned long long)g->N * Hp * Wp;
     const unsigned long long xb = (unsigned long long)g->N * g->H * g->W * g->C * 2ull, gb = (unsigned long long)g->N * g->H * g->W * g->K * 2ull;
@@ -266,7 +267,7 @@ bool plan(const CsConvGeom* g, int dtype, int n_items, W2Plan& pl) {
 template <int BL, int XR>
 int launch_t(const W2Params& p, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)(BL + XR) * 128;
-    if (!cs_allow_dynamic_lds_(reinterpret_cast<const void*>(wgrad2_kernel<BL, XR>), lds, 81920)) return CS_ERR_LAUNCH;
+    if (!cs_allow_dynamic_lds_(reinterpret_cast<const void*>(wgrad2_kernel<BL, XR>), lds, lds > 81920 ? 163840 : 81920)) return CS_ERR_LAUNCH;
     char name[48];
     snprintf(name, sizeof(name), "wgrad2_kernel<%d,%d>", BL, XR);
     cs_set_variant_(name);
@@ -298,5 +299,6 @@ int cs_wgrad2_launch_(const CsConvGeom* g, int dtype, const void* const* x_tab, 
     if (pl.bl == 128 && pl.xr == 152) return launch_t<128, 152>(pl.p, st);
     if (pl.bl == 128) return launch_t<128, 176>(pl.p, st);
     if (pl.xr == 144) return launch_t<64, 144>(pl.p, st);
+    if (pl.xr == 384) return launch_t<64, 384>(pl.p, st);
     return launch_t<64, 224>(pl.p, st);
 }

@@ -168,7 +168,7 @@ int cs_conv2d_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* d
  * are passed to the kernel by value, no device table, no copy); dw_tab[i] is a [nsplit][K][R][S][Cp] fp32 buffer. */
 int cs_conv2d_wgrad_batched_splits(const CsConvGeom* g, int dtype, int n_items);
 /* 1 when cs_conv2d_wgrad_batched serves this geometry with the second-generation kernel (wgrad_v2.hip: bf16, stride-1 pad-1 3x3,
- * C and K multiples of 64, image width <= 78): callers with a single layer then prefer the batched entry (n_items = 1). */
+ * C and K multiples of 64, image width <= 158): callers with a single layer then prefer the batched entry (n_items = 1). */
 int cs_conv2d_wgrad2_supported(const CsConvGeom* g, int dtype);
 int cs_conv2d_wgrad_batched(const CsConvGeom* g, int dtype, const void* const* x_tab, const void* const* dy_tab,
                             float* const* dw_tab, int n_items, int use_tr_read, void* stream);

@@ -26,6 +26,8 @@ SHAPES = [
     (2, 12, 12, 64, 128, 3, 1, 0),      # valid convolution: the data gradient's source is smaller than its destination
     (2, 9, 9, 64, 128, 3, 1, 2),        # pad 2: output larger than input
     (3, 21, 17, 192, 128, 3, 1, 1),     # three chunks
+    (1, 150, 150, 128, 128, 3, 1, 1),   # wide image (the 150 x 150 decoder layers): 6-7 window blocks per wave, two stages, one workgroup per CU
+    (1, 131, 97, 256, 128, 3, 1, 1),    # the same with four chunks, non-square
     # 1x1: the persistent ring kernel (any contraction depth): (pixel tile, 64-channel chunk) steps over three LDS slots
     (2, 19, 19, 64, 256, 1, 1, 0),      # one chunk (an epilogue every step); data gradient: four chunks into 64 channels (2 x 2 waves)
     (3, 21, 17, 256, 64, 1, 1, 0),      # four chunks into 64 channels; data gradient: one chunk, 1 x 4 waves

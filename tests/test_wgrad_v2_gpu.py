@@ -21,6 +21,8 @@ SHAPES = [
     (5, 7, 9, 64, 128, 1),         # non-square, tiny images: several images per stage
     (1, 21, 17, 192, 64, 1),       # three source chunks, one image
     (64, 10, 10, 512, 512, 1),     # layer4 at bench size: 64 tile pairs, few splits
+    (1, 150, 150, 128, 64, 1),     # the widest decoder layer (upconv8, resnet.py:163): Wp = 151, the 384-row x region (one workgroup per CU)
+    (2, 97, 131, 64, 128, 2),      # Wp = 132, non-square, two layers
 ]
 
 
