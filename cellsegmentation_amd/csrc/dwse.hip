@@ -745,6 +745,111 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const bf16_t* __res
     }
 }
 
+// Forward (FLIP = false) and stride-1 data gradient (FLIP = true: source dy, pad' = R - 1 - pad, mirrored filter) on strips: the thread's
+// R*R filter pairs stay in registers (its channel pair is fixed), TS accumulators, one unpacked input row at a time.
+// STATS: per-channel sum / sum of squares of the STORED values, partial[(2 * blockIdx.x + {0,1}) * C + c] in fp64 (cs_bn_partial_fold).
+template <int R, int ST, int TS, bool STATS, bool FLIP>
+__global__ __launch_bounds__(256) void dw_conv_strip_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int act, bf16_t* __restrict__ y,
+                                                            double* __restrict__ partial, int N, int H, int W, int C, int pad, int P, int Q,
+                                                            int items_per_block, int cpt, unsigned x_bytes, unsigned y_bytes) {
+    constexpr int NC = (TS - 1) * ST + R;
+    __shared__ v2f red[STATS ? 2 : 1][STATS ? 256 : 1];
+    const int npl = 256 / cpt;
+    const int cpl = threadIdx.x % cpt, pl = threadIdx.x / cpt;
+    const int CP = C / 2;
+    const int cp = blockIdx.y * cpt + cpl;
+    const bool live = cp < CP && pl < npl;
+    const int QS = (Q + TS - 1) / TS;
+    const long long total = (long long)N * P * QS;
+    const long long i0 = (long long)blockIdx.x * items_per_block;
+    long long i1 = i0 + items_per_block;
+    if (i1 > total) i1 = total;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
+    const unsigned Cb = (unsigned)C * 2u;
+    v2f s1 = v2f{0.f, 0.f}, s2 = v2f{0.f, 0.f};
+    if (live) {
+        v2f wv[R * R];
+#pragma unroll
+        for (int t = 0; t < R * R; ++t) {
+            const float2 f = *reinterpret_cast<const float2*>(w + (long long)(FLIP ? R * R - 1 - t : t) * C + 2 * cp);
+            wv[t] = v2f{f.x, f.y};
+        }
+        v2f sc = v2f{1.f, 1.f}, sh = v2f{0.f, 0.f};
+        if (scale) { const float2 f = *reinterpret_cast<const float2*>(scale + 2 * cp); sc = v2f{f.x, f.y}; }
+        if (shift) { const float2 f = *reinterpret_cast<const float2*>(shift + 2 * cp); sh = v2f{f.x, f.y}; }
+        for (long long it = i0 + pl; it < i1; it += npl) {
+            const int sx = (int)(it % QS);
+            const long long t_ = it / QS;
+            const int oy = (int)(t_ % P);
+            const int n = (int)(t_ / P);
+            const int ox0 = sx * TS;
+            unsigned co[NC];
+            const int ixb = ox0 * ST - pad;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) co[j] = (unsigned)(ixb + j) < (unsigned)W ? (unsigned)(ixb + j) * Cb + (unsigned)cp * 4u : kDwColOut;
+            auto row_base = [&](int kh) -> unsigned {
+                const int iy = oy * ST - pad + kh;
+                return (unsigned)iy < (unsigned)H ? (unsigned)((n * H + iy) * W) * Cb : kDwRowOut;
+            };
+            unsigned raw[2][NC];
+            {
+                const unsigned rb = row_base(0);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) raw[0][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, rb + co[j], 0, 0);
+            }
+            v2f acc[TS];
+#pragma unroll
+            for (int j = 0; j < TS; ++j) acc[j] = v2f{0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < R; ++kh) {
+                if (kh + 1 < R) {
+                    const unsigned rb = row_base(kh + 1);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) raw[(kh + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, rb + co[j], 0, 0);
+                }
+                v2f xv[NC];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) xv[j] = bf2_unpack(raw[kh & 1][j]);
+#pragma unroll
+                for (int kw = 0; kw < R; ++kw)
+#pragma unroll
+                    for (int j = 0; j < TS; ++j) acc[j] = __builtin_elementwise_fma(xv[j * ST + kw], wv[kh * R + kw], acc[j]);
+            }
+            const unsigned yb = (unsigned)((n * P + oy) * Q + ox0) * Cb + (unsigned)cp * 4u;
+#pragma unroll
+            for (int j = 0; j < TS; ++j) {
+                v2f v = __builtin_elementwise_fma(acc[j], sc, sh);
+                if (act == CS_ACT_RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; }
+                else if (act == CS_ACT_SILU) { v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y)); }
+                const unsigned u = pack_bf16x2(v.x, v.y);
+                const bool in = ox0 + j < Q;
+                __builtin_amdgcn_raw_buffer_store_b32(u, ry, in ? yb + (unsigned)j * Cb : kDwRowOut, 0, 0);
+                if constexpr (STATS) {
+                    const v2f r = in ? bf2_unpack(u) : v2f{0.f, 0.f};          // statistics of the stored (rounded) values
+                    s1 += r;
+                    s2 = __builtin_elementwise_fma(r, r, s2);
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (pl == 0 && live) {
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+            for (int r = 0; r < npl; ++r) {
+                const v2f u1 = red[0][r * cpt + cpl], u2 = red[1][r * cpt + cpl];
+                a0 += (double)u1.x; a1 += (double)u1.y; b0 += (double)u2.x; b1 += (double)u2.y;
+            }
+            double* d0 = partial + (2LL * blockIdx.x) * C + 2 * cp;
+            double* d1 = partial + (2LL * blockIdx.x + 1) * C + 2 * cp;
+            d0[0] = a0; d0[1] = a1; d1[0] = b0; d1[1] = b1;
+        }
+    }
+}
+
 // channel-pair tile of the strip kernels: cpt lanes x (256 / cpt) item lanes; the tile that keeps most lanes busy, at least 16 pairs
 // (64 contiguous bytes per pixel)
 inline void dw_strip_shape(int C, int& chunks, int& cpt) {
@@ -820,6 +925,57 @@ static void launch_dw_tile(int R, int ST, hipStream_t st, const void* x, const f
     else CS_DW_TILE(5, 2);
 #undef CS_DW_TILE
 }
+// ---- strip kernels (bf16): geometry of a launch over (source N x H x W) -> (destination N x P x Q)
+struct DwStrip { int ts, per, chunks, cpt; unsigned nblk; };
+static bool dw_strip_ok(int R, int stride, long long src_elems, long long dst_elems, int dtype) {
+    static const int off = cs_env_int_("CELLSEG_DW_NOSTRIP", 0);      // A/B experiments only
+    return !off && dtype == CS_BF16 && (R == 3 || R == 5) && (stride == 1 || stride == 2) && src_elems * 2 < (1ll << 30) && dst_elems * 2 < (1ll << 30);
+}
+// strip length: the one of the two instantiated per stride that wastes fewer columns; `blocks_target` workgroups in all
+static DwStrip dw_strip_plan(int N, int P, int Q, int C, int stride, long long blocks_target, long long rows_cap) {
+    DwStrip d;
+    const int a = stride == 1 ? 8 : 4, b = 5;
+    const int wa = (Q + a - 1) / a * a, wb = (Q + b - 1) / b * b;
+    d.ts = wb < wa ? b : a;
+    dw_strip_shape(C, d.chunks, d.cpt);
+    const long long items = (long long)N * P * ((Q + d.ts - 1) / d.ts);
+    long long blocks = blocks_target / d.chunks;
+    if (blocks < 1) blocks = 1;
+    if (rows_cap > 0 && blocks > rows_cap) blocks = rows_cap;
+    long long p_ = (items + blocks - 1) / blocks;
+    const int npl = 256 / d.cpt;
+    if (p_ < 2 * npl) p_ = 2 * npl;
+    d.per = (int)p_;
+    d.nblk = (unsigned)((items + p_ - 1) / p_);
+    return d;
+}
+// forward launches that stay on the channel-tiled kernel: the 144-channel 3x3 stride-2 layer at 150 x 150 (194 vs 231 us, tools/dw_microbench.py)
+static bool dw_strip_fwd_ok(const CsConvGeom* g, int dtype) {
+    if (g->stride == 2 && g->R == 3 && g->C <= 144 && dw_tiled_geometry(g, 0)) return false;
+    return dw_strip_ok(g->R, g->stride, (long long)g->N * g->H * g->W * g->C, (long long)g->N * g->P * g->Q * g->C, dtype);
+}
+static DwStrip dw_strip_plan_conv(int N, int P, int Q, int C, int stride) {
+    return dw_strip_plan(N, P, Q, C, stride, 4096, 2048);            // (partial statistics rows: at most 2048 per launch)
+}
+template <bool STATS, bool FLIP>
+static void launch_dw_strip(int R, int ST, hipStream_t st, const void* x, const float* w, const float* scale, const float* shift, int act,
+                            void* y, double* partial, int N, int H, int W, int C, int pad, int P, int Q, int* rows_out) {
+    const DwStrip d = dw_strip_plan_conv(N, P, Q, C, ST);
+    if (rows_out) *rows_out = (int)d.nblk;
+    const unsigned xb = (unsigned)((long long)N * H * W * C * 2), yb = (unsigned)((long long)N * P * Q * C * 2);
+#define CS_DW_CS(R_, S_, T_)                                                                                                              \
+    hipLaunchKernelGGL((dw_conv_strip_kernel<R_, S_, T_, STATS, FLIP>), dim3(d.nblk, (unsigned)d.chunks), dim3(256), 0, st, (const bf16_t*)x, w, \
+                       scale, shift, act, (bf16_t*)y, partial, N, H, W, C, pad, P, Q, d.per, d.cpt, xb, yb)
+    if (R == 3) {
+        if (ST == 1) { if (d.ts == 8) CS_DW_CS(3, 1, 8); else CS_DW_CS(3, 1, 5); }
+        else { if (d.ts == 4) CS_DW_CS(3, 2, 4); else CS_DW_CS(3, 2, 5); }
+    } else {
+        if (ST == 1) { if (d.ts == 8) CS_DW_CS(5, 1, 8); else CS_DW_CS(5, 1, 5); }
+        else { if (d.ts == 4) CS_DW_CS(5, 2, 4); else CS_DW_CS(5, 2, 5); }
+    }
+#undef CS_DW_CS
+}
+
 static int dw_tile_rows(const CsConvGeom* g) {
     int chunks, cgt;
     dw_tile_shape(g->C, chunks, cgt);
@@ -843,6 +999,11 @@ extern "C" int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, cons
     if (rc) return rc;
     CS_CHECK_ARG(x && w_hwc && y, "dwconv_fwd: NULL tensor");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_strip_fwd_ok(g, dtype)) {
+        launch_dw_strip<false, false>(g->R, g->stride, st, x, w_hwc, scale, shift, act, y, nullptr, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, nullptr);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dw_tiled_geometry(g, 0) && (dtype == CS_F32 || dtype == CS_BF16)) {
         if (dtype == CS_F32) launch_dw_tile<float, false, false>(g->R, g->stride, st, x, w_hwc, scale, shift, act, y, nullptr, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, nullptr);
         else launch_dw_tile<bf16_t, false, false>(g->R, g->stride, st, x, w_hwc, scale, shift, act, y, nullptr, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, nullptr);
@@ -874,16 +1035,23 @@ static int dw_stats_grid(const CsConvGeom* g) {
 
 extern "C" size_t cs_dwconv_fwd_stats_workspace(const CsConvGeom* g) {
     if (!g || g->C <= 0 || g->C % 8) return 0;
-    if (dw_tiled_geometry(g, 0)) return (size_t)dw_tile_rows(g) * 2 * (size_t)g->C * sizeof(double);
-    return (size_t)dw_stats_grid(g) * 2 * (size_t)g->C * sizeof(double);
+    size_t strip_rows = 0;                               // (the dtype is not known here: room for whichever kernel serves the call)
+    if (dw_strip_fwd_ok(g, CS_BF16))
+        strip_rows = dw_strip_plan_conv(g->N, g->P, g->Q, g->C, g->stride).nblk;
+    const size_t other_rows = dw_tiled_geometry(g, 0) ? (size_t)dw_tile_rows(g) : (size_t)dw_stats_grid(g);
+    return (strip_rows > other_rows ? strip_rows : other_rows) * 2 * (size_t)g->C * sizeof(double);
 }
-
 extern "C" int cs_dwconv_fwd_stats(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, void* y, double* partial,
                                    int* partial_rows, void* stream) {
     int rc = check_dw(g, "dwconv_fwd_stats: bad geometry (square filter, K == C, C % 8 == 0 required)");
     if (rc) return rc;
     CS_CHECK_ARG(x && w_hwc && y && partial && partial_rows, "dwconv_fwd_stats: NULL argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_strip_fwd_ok(g, dtype)) {
+        launch_dw_strip<true, false>(g->R, g->stride, st, x, w_hwc, nullptr, nullptr, CS_ACT_NONE, y, partial, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, partial_rows);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dw_tiled_geometry(g, 0) && (dtype == CS_F32 || dtype == CS_BF16)) {
         if (dtype == CS_F32) launch_dw_tile<float, true, false>(g->R, g->stride, st, x, w_hwc, nullptr, nullptr, CS_ACT_NONE, y, partial, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, partial_rows);
         else launch_dw_tile<bf16_t, true, false>(g->R, g->stride, st, x, w_hwc, nullptr, nullptr, CS_ACT_NONE, y, partial, g->N, g->H, g->W, g->C, g->pad, g->P, g->Q, partial_rows);
@@ -908,6 +1076,12 @@ extern "C" int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, c
     if (rc) return rc;
     CS_CHECK_ARG(dy && w_hwc && dx, "dwconv_dgrad: NULL tensor");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (g->stride == 1 && g->pad <= g->R - 1 && dw_strip_ok(g->R, 1, (long long)g->N * g->P * g->Q * g->C, (long long)g->N * g->H * g->W * g->C, dtype)) {
+        // the gradient of a stride-1 convolution is the same convolution with the filter mirrored (source dy, destination dx)
+        launch_dw_strip<false, true>(g->R, 1, st, dy, w_hwc, nullptr, nullptr, CS_ACT_NONE, dx, nullptr, g->N, g->P, g->Q, g->C, g->R - 1 - g->pad, g->H, g->W, nullptr);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dw_tiled_geometry(g, 1) && (dtype == CS_F32 || dtype == CS_BF16)) {
         if (g->stride == 1) {
             // the gradient of a stride-1 "same" convolution is the same convolution with the filter mirrored (source dy, destination dx)
