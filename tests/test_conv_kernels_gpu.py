@@ -292,3 +292,23 @@ def test_wave_specialised_weight_gradient_on_every_shape(dev):
                             os.path.join(root, "tests", "test_conv_packed_gpu.py"), "-m", "gpu", "-x", "-q",
                             "-k", "not wave_specialised"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(70, 100, 3, 72, 104), (600, 520, 3, 608, 520), (512, 1024, 3, 512, 1024), (128, 96, 1, 128, 96), (40, 328, 5, 40, 328), (2048, 1024, 1, 2048, 1024), (2050, 1030, 1, 2056, 1032)])
+def test_weight_prep_tiled_layouts(shape, dev):
+    """The LDS-tiled bf16 weight staging (prep.hip weight_prep_tiled_kernel) against a permute: both layouts, padded channels zero,
+    per-filter scale applied before the rounding."""
+    Kc, Cin, R, Kp, Cp = shape
+    g = torch.Generator().manual_seed(Kc * 13 + Cin)
+    w = torch.randn((Kc, Cin, R, R), generator=g)
+    scale = torch.rand((Kc,), generator=g) + 0.5
+    for sc in (None, scale):
+        wk, wc = K.weight_prep(w.to(dev), None if sc is None else sc.to(dev), torch.bfloat16, Cp, Kp, want_fwd=True, want_bwd=True)
+        ws = w if sc is None else w * sc.view(-1, 1, 1, 1)
+        ref_k = torch.zeros((Kp, R, R, Cp), dtype=torch.bfloat16)
+        ref_k[:Kc, :, :, :Cin] = ws.permute(0, 2, 3, 1).to(torch.bfloat16)
+        ref_c = torch.zeros((Cp, R, R, Kp), dtype=torch.bfloat16)
+        ref_c[:Cin, :, :, :Kc] = ws.permute(1, 2, 3, 0).to(torch.bfloat16)
+        assert torch.equal(wk.cpu().view(Kp, R, R, Cp), ref_k)
+        assert torch.equal(wc.cpu().view(Cp, R, R, Kp), ref_c)
