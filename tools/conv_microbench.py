@@ -30,6 +30,8 @@ SHAPES = {
     "l3_1x1_s2_512_1024": (64, 38, 38, 512, 1024, 1, 2, 0),
     "l4_1x1_s2_1024_2048": (64, 19, 19, 1024, 2048, 1, 2, 0),
     "l2_3x3_s2": (64, 75, 75, 128, 128, 3, 2, 1),
+    "l3_3x3_s2": (64, 38, 38, 256, 256, 3, 2, 1),
+    "l4_3x3_s2": (64, 19, 19, 512, 512, 3, 2, 1),
     "dec_3x3_2048_1024": (8, 19, 19, 2048, 1024, 3, 1, 1),
 }
 
