@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             } else if (act == CS_ACT_SILU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+                for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
             }
             store8<T>(y + off, v);
         };
@@ -164,11 +164,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
 
 // gradient through the activation that follows the normalisation: ReLU is handled by the consumers' masks
 // (engine convention), SiLU needs u = gamma*xhat + beta: d silu(u)/du = sig*(1 + u*(1-sig)).
-__device__ __forceinline__ float act_grad(float g, float xh, float gm, float bt, int act) {
-    if (act != CS_ACT_SILU) return g;
-    const float u = gm * xh + bt;
-    const float sg = 1.f / (1.f + __expf(-u));
-    return g * sg * (1.f + u * (1.f - sg));
+// eight elements at once with ONE branch on the activation: a branch per element makes every exp -> add -> rcp chain its own basic
+// block, and the eight chains run back to back instead of interleaved
+__device__ __forceinline__ void act_grad8(float (&g)[8], const float (&xh)[8], const float (&gm)[8], const float (&bt)[8], int act) {
+    if (act != CS_ACT_SILU) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float u = gm[e] * xh[e] + bt[e];
+        const float sg = sigmoid_fast(u);
+        g[e] = g[e] * sg * (1.f + u * (1.f - sg));
+    }
 }
 
 template <typename T>
@@ -196,13 +201,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             load8p(rstd + cg * 8, 1.f, rs);
             load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
             load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
-            auto acc = [&](const float (&g)[8], const float (&zz)[8]) {
+            auto acc = [&](float (&g)[8], const float (&zz)[8]) {
+                float xh[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xh = (zz[e] - mu[e]) * rs[e];
-                    const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
-                    s0[e] += gu; s1[e] += gu * xh;
-                }
+                for (int e = 0; e < 8; ++e) xh[e] = (zz[e] - mu[e]) * rs[e];
+                act_grad8(g, xh, gm, bt, act);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * xh[e]; }
             };
             long long r = r0 + rr;
             for (; r + rpar < r1; r += 2LL * rpar) {             // four independent 16-byte loads in flight per thread
@@ -260,14 +265,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             k1[e] = (float)sums[C + cg * 8 + e] * invM;
             gr[e] = gm[e] * rs[e];
         }
-        auto finish = [&](const float (&g)[8], const float (&zz)[8], const long long off) {
-            float o[8];
+        auto finish = [&](float (&g)[8], const float (&zz)[8], const long long off) {
+            float o[8], xh[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xh = (zz[e] - mu[e]) * rs[e];
-                const float gu = act_grad(g[e], xh, gm[e], bt[e], act);
-                o[e] = gr[e] * (gu - k0[e] - xh * k1[e]);
-            }
+            for (int e = 0; e < 8; ++e) xh[e] = (zz[e] - mu[e]) * rs[e];
+            act_grad8(g, xh, gm, bt, act);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gr[e] * (g[e] - k0[e] - xh[e] * k1[e]);
             store8<T>(dz + off, o);
         };
         long long r = r0 + rr;

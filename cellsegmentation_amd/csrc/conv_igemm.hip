@@ -243,7 +243,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 } else if (p.act == CS_ACT_SILU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+                    for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
                 }
                 if (p.bits_in) {
                     unsigned mb;

@@ -84,6 +84,12 @@ __device__ __forceinline__ void load8p(const float* p, float fill, float (&v)[8]
     }
 }
 
+// SiLU / sigmoid with the hardware reciprocal (1 ulp) instead of an IEEE division: `a / b` compiles to v_div_scale x2, v_rcp, four
+// FMAs, v_div_fmas, v_div_fixup -- 53 VALU instructions per element made the BatchNorm backward passes of the EfficientNet path
+// instruction-bound at 2.7 TB/s (round 3).  The result is rounded to bf16 (or feeds a gradient that is), 2e-7 relative is noise.
+__device__ __forceinline__ float sigmoid_fast(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
+__device__ __forceinline__ float silu_fast(float u) { return u * sigmoid_fast(u); }
+
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }

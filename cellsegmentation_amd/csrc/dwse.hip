@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, co
         for (int e = 0; e < 8; ++e) {
             float v = acc[e] * sc8[e] + sh8[e];
             if (act == CS_ACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (act == CS_ACT_SILU) v = v / (1.f + __expf(-v));
+            else if (act == CS_ACT_SILU) v = silu_fast(v);
             acc[e] = v;
         }
         store8<T>(y + ((n * P + oy) * (long long)Q + ox) * C + cg * 8, acc);
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ x, c
             for (int e = 0; e < 8; ++e) {
                 float v0 = a0[e] * sc8[e] + sh8[e], v1 = a1[e] * sc8[e] + sh8[e];
                 if (act == CS_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-                else if (act == CS_ACT_SILU) { v0 = v0 / (1.f + __expf(-v0)); v1 = v1 / (1.f + __expf(-v1)); }
+                else if (act == CS_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); }
                 a0[e] = v0; a1[e] = v1;
             }
             T* orow = y + ((n * P + oy) * (long long)Q + ox0) * C + cg * 8;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const bf16_t* __rest
             for (int j = 0; j < TS; ++j) {
                 v2f v = __builtin_elementwise_fma(acc[j], sc, sh);
                 if (act == CS_ACT_RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; }
-                else if (act == CS_ACT_SILU) { v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y)); }
+                else if (act == CS_ACT_SILU) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
                 const unsigned u = pack_bf16x2(v.x, v.y);
                 const bool in = ox0 + j < Q;
                 __builtin_amdgcn_raw_buffer_store_b32(u, ry, in ? yb + (unsigned)j * Cb : kDwRowOut, 0, 0);
