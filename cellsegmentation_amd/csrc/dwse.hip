@@ -678,11 +678,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const bf16_t* __res
 #pragma unroll
     for (int t = 0; t < R * R; ++t) acc[t] = v2f{0.f, 0.f};
     if (live) {
+        // (item -> (n, oy, strip) once, then carried: 64-bit divisions per item cost as much as a 3x3 item's arithmetic)
+        int sx, oy, n;
+        {
+            const unsigned first = (unsigned)(i0 + pl);
+            const unsigned t_ = first / (unsigned)QS;
+            sx = (int)(first - t_ * (unsigned)QS);
+            n = (int)(t_ / (unsigned)P);
+            oy = (int)(t_ - (unsigned)n * (unsigned)P);
+        }
         for (long long it = i0 + pl; it < i1; it += npl) {
-            const int sx = (int)(it % QS);
-            const long long t_ = it / QS;
-            const int oy = (int)(t_ % P);
-            const int n = (int)(t_ / P);
             const int ox0 = sx * TS;
             // column offsets of the x window (padding columns pushed out of range) -- one set per item, shared by its R rows
             unsigned co[NC];
@@ -722,6 +727,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(const bf16_t* __res
 #pragma unroll
                     for (int j = 0; j < TS; ++j) acc[kh * R + kw] = __builtin_elementwise_fma(g[j], xv[j * ST + kw], acc[kh * R + kw]);
             }
+            sx += npl;
+            while (sx >= QS) { sx -= QS; if (++oy == P) { oy = 0; ++n; } }
         }
     }
     // fold the item lanes through LDS, TB taps per pass; thread (tap, channel pair) writes slab[blockIdx.x][tap][2cp .. 2cp+1]
@@ -779,11 +786,16 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const bf16_t* __rest
         v2f sc = v2f{1.f, 1.f}, sh = v2f{0.f, 0.f};
         if (scale) { const float2 f = *reinterpret_cast<const float2*>(scale + 2 * cp); sc = v2f{f.x, f.y}; }
         if (shift) { const float2 f = *reinterpret_cast<const float2*>(shift + 2 * cp); sh = v2f{f.x, f.y}; }
+        // (item -> (n, oy, strip) once, then carried: 64-bit divisions per item cost as much as a 3x3 item's arithmetic)
+        int sx, oy, n;
+        {
+            const unsigned first = (unsigned)(i0 + pl);
+            const unsigned t_ = first / (unsigned)QS;
+            sx = (int)(first - t_ * (unsigned)QS);
+            n = (int)(t_ / (unsigned)P);
+            oy = (int)(t_ - (unsigned)n * (unsigned)P);
+        }
         for (long long it = i0 + pl; it < i1; it += npl) {
-            const int sx = (int)(it % QS);
-            const long long t_ = it / QS;
-            const int oy = (int)(t_ % P);
-            const int n = (int)(t_ / P);
             const int ox0 = sx * TS;
             unsigned co[NC];
             const int ixb = ox0 * ST - pad;
@@ -832,6 +844,8 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const bf16_t* __rest
                     s2 = __builtin_elementwise_fma(r, r, s2);
                 }
             }
+            sx += npl;
+            while (sx >= QS) { sx -= QS; if (++oy == P) { oy = 0; ++n; } }
         }
     }
     if constexpr (STATS) {
