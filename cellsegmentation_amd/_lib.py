@@ -88,6 +88,7 @@ _SIGNATURES = {
     "cs_bn_partial_workspace": (c_size_t, [c_longlong, c_int]),
     "cs_bn_finalize": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P, _P, c_int, _P]),
     "cs_bn_apply": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_longlong, c_int, _P]),
+    "cs_bn_apply_stats": (c_int, [_P, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_longlong, c_int, _P]),
     "cs_bn_bwd_reduce": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_longlong, c_int, _P, _P, _P]),
     "cs_bn_bwd_apply": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_longlong, c_int, _P, _P, _P, _P]),
     "cs_dwconv_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, c_int, _P, _P]),

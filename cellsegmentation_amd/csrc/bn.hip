@@ -84,33 +84,58 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, 
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long M, float eps, float momentum,
-                                   float* running_mean, float* running_var, float* __restrict__ mean_out,
-                                   float* __restrict__ rstd_out, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = stats[c] / (double)M;
-    double var = stats[C + c] / (double)M - mean * mean;
+// batch mean / 1/sqrt(var + eps) of one channel from its fp64 sums: ONE definition for cs_bn_finalize and for the apply pass that
+// derives them itself (cs_bn_apply_stats), so both give the same bits
+__device__ __forceinline__ void bn_moments(double s0, double s1, long long M, float eps, float& mean_f, float& rstd_f, double& var_out) {
+    const double mean = s0 / (double)M;
+    double var = s1 / (double)M - mean * mean;
     if (var < 0) var = 0;
-    mean_out[c] = (float)mean;
-    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    mean_f = (float)mean;
+    rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    var_out = var;
+}
+__device__ __forceinline__ void bn_finalize_channel(const double* __restrict__ stats, int c, int C, long long M, float eps, float momentum,
+                                                    float* running_mean, float* running_var, float* __restrict__ mean_out,
+                                                    float* __restrict__ rstd_out) {
+    float mean, rstd;
+    double var;
+    bn_moments(stats[c], stats[C + c], M, eps, mean, rstd, var);
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     if (running_var) {
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
 }
 
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long M, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    bn_finalize_channel(stats, c, C, M, eps, momentum, running_mean, running_var, mean_out, rstd_out);
+}
+
 // Row-strided element-wise passes (round 3): a thread keeps ONE 8-channel group and walks rows r0 + rr, r0 + rr + rpar, ... of its
 // workgroup's row block, so every per-channel constant is loaded and combined once per thread -- round 2's flat index walk re-read
 // 4-6 parameter vectors (and, in the backward apply, 16 fp64 sums) per 16 bytes of data: instruction-bound at 1.8-2.3 TB/s on the
 // EfficientNet-B3 step.  Two rows (4-6 independent 16-byte loads) are in flight per thread.
+// fin.stats != NULL (cs_bn_apply_stats): the launch also IS the finalize -- every thread derives mean / rstd of its 8 channels from the
+// fp64 sums (bn_moments), workgroup 0 writes them out and updates the running statistics: one launch less per train-mode BatchNorm
+// (78 per EfficientNet-B3 step, 61 per segmentation step).
+struct BnFinalizeArgs {
+    const double* stats; long long M; float eps, momentum; float* running_mean; float* running_var; float* mean_out; float* rstd_out;
+};
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual,
-                                                       int act, T* __restrict__ y, long long M, int C, int rows_per_block) {
+                                                       int act, T* __restrict__ y, long long M, int C, int rows_per_block, BnFinalizeArgs fin) {
     const int CG = C / 8;
+    if (fin.stats && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256)
+            bn_finalize_channel(fin.stats, c, C, fin.M, fin.eps, fin.momentum, fin.running_mean, fin.running_var, fin.mean_out, fin.rstd_out);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
@@ -121,8 +146,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
         const int rr = threadIdx.x / width;
         if (rr >= rpar) continue;
         float mu[8], rs[8], gm[8], bt[8];
-        load8p(mean + cg * 8, 0.f, mu);
-        load8p(rstd + cg * 8, 1.f, rs);
+        if (fin.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                double var;
+                bn_moments(fin.stats[cg * 8 + e], fin.stats[C + cg * 8 + e], fin.M, fin.eps, mu[e], rs[e], var);
+            }
+        } else {
+            load8p(mean + cg * 8, 0.f, mu);
+            load8p(rstd + cg * 8, 1.f, rs);
+        }
         load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
         load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
         auto finish = [&](float (&v)[8], const long long off) {
@@ -401,12 +434,31 @@ extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const fl
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rpb = ew_rows_per_block(M, C);
     const int grid = (int)((M + rpb - 1) / rpb);
+    const BnFinalizeArgs fin{};
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, mean, rstd, gamma, beta,
-                                     (const float*)residual, act, (float*)y, M, C, rpb),
+                                     (const float*)residual, act, (float*)y, M, C, rpb, fin),
                   hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)z, mean, rstd, gamma, beta,
-                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, rpb),
+                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, rpb, fin),
                   "bn_apply");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_bn_apply_stats(const void* z, int dtype, const double* stats, float eps, float momentum, float* running_mean,
+                                 float* running_var, const float* gamma, const float* beta, const void* residual, int act, void* y,
+                                 float* mean_out, float* rstd_out, long long M, int C, void* stream) {
+    CS_CHECK_ARG(z && y && stats && mean_out && rstd_out && M > 0 && C > 0 && C % 8 == 0, "bn_apply_stats: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = ew_rows_per_block(M, C);
+    const int grid = (int)((M + rpb - 1) / rpb);
+    const BnFinalizeArgs fin{stats, M, eps, momentum, running_mean, running_var, mean_out, rstd_out};
+    CS_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, nullptr, nullptr, gamma, beta,
+                                     (const float*)residual, act, (float*)y, M, C, rpb, fin),
+                  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)z, nullptr, nullptr, gamma, beta,
+                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, rpb, fin),
+                  "bn_apply_stats");
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -389,11 +389,12 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                     z = K.conv_fwd(geom, x, st.w_khwc, None, st.shift, None, ACT_NONE, stats=stats, grouped=u.grouped)
                 M = N * geom.P * geom.Q
                 momentum = bn.momentum if bn.momentum is not None else 0.1
-                mean, rstd = K.bn_finalize(stats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
-                                           bn.running_var if bn.track_running_stats else None)
+                # (finalize + apply in one launch: mean / rstd are derived from the sums inside the apply pass)
+                y, mean, rstd = K.bn_apply_stats(z, stats, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
+                                                 bn.running_var if bn.track_running_stats else None, bn.weight.detach(), bn.bias.detach(),
+                                                 res, u.act)
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
                     bumped.append(bn.num_batches_tracked)
-                y = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), res, u.act)
                 aux[ui] = SimpleNamespace(geom=geom, st=st, train=True, z=z if save else None, mean=mean, rstd=rstd, xp=xp)
             t[u.dst] = y
         elif u.kind == "dw":
@@ -407,11 +408,11 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                 z, zstats = K.dwconv_fwd_stats(geom, x, w_hwc)
                 M = N * geom.P * geom.Q
                 momentum = bn.momentum if bn.momentum is not None else 0.1
-                mean, rstd = K.bn_finalize(zstats, M, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
-                                           bn.running_var if bn.track_running_stats else None)
+                t[u.dst], mean, rstd = K.bn_apply_stats(z, zstats, bn.eps, momentum, bn.running_mean if bn.track_running_stats else None,
+                                                        bn.running_var if bn.track_running_stats else None, bn.weight.detach(),
+                                                        bn.bias.detach(), None, u.act)
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
                     bumped.append(bn.num_batches_tracked)
-                t[u.dst] = K.bn_apply(z, mean, rstd, bn.weight.detach(), bn.bias.detach(), None, u.act)
                 aux[ui] = SimpleNamespace(geom=geom, train=True, z=z if save else None, mean=mean, rstd=rstd, w_hwc=w_hwc)
             else:
                 scale, shift, _ = K.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)

@@ -622,6 +622,17 @@ def bn_apply(z, mean, rstd, gamma, beta, residual=None, act=CS_ACT_NONE, out=Non
     return y
 
 
+def bn_apply_stats(z, stats, eps, momentum, running_mean, running_var, gamma, beta, residual=None, act=CS_ACT_NONE):
+    """bn_finalize + bn_apply as one launch: returns (y, mean, rstd); the running statistics (nullable) are updated in place."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    y = torch.empty_like(z)
+    out = torch.empty((2, C), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().cs_bn_apply_stats(_p(z), _code(z.dtype), _p(stats), eps, momentum, _p(running_mean), _p(running_var), _p(gamma),
+                                             _p(beta), _p(residual), act, _p(y), _p(out[0]), _p(out[1]), M, C, _stream()), "bn_apply_stats")
+    return y, out[0], out[1]
+
+
 def bn_bwd(dy, z, mean, rstd, gamma, want_param_grads=True, beta=None, act=CS_ACT_NONE):
     """returns dz, dgamma, dbeta.  act=CS_ACT_SILU differentiates through the SiLU that follows the BN."""
     C = z.shape[-1]

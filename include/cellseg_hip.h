@@ -77,6 +77,13 @@ int cs_bn_finalize(const double* stats, long long M, float eps, float momentum, 
 /* y = act( gamma*(z-mean)*rstd + beta + residual ); gamma/beta/residual nullable. */
 int cs_bn_apply(const void* z, int dtype, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream);
+/* cs_bn_finalize + cs_bn_apply in ONE launch (train-mode forward of nn.BatchNorm2d, model/resnet.py:150 / efficientnet.py:93 with
+ * module.training): every thread derives mean and 1/sqrt(var + eps) of its channels from the fp64 sums `stats` [2][C] with the same
+ * arithmetic as cs_bn_finalize (bit-identical results), workgroup 0 writes mean_out / rstd_out (kept for backward) and updates the
+ * running statistics (nullable). */
+int cs_bn_apply_stats(const void* z, int dtype, const double* stats, float eps, float momentum, float* running_mean,
+                      float* running_var, const float* gamma, const float* beta, const void* residual, int act, void* y,
+                      float* mean_out, float* rstd_out, long long M, int C, void* stream);
 /* sums fp64 [2][C] (zeroed by caller): sum g, sum g*xhat with xhat=(z-mean)*rstd and g = dy, or for
  * act==CS_ACT_SILU g = dy*silu'(gamma*xhat+beta) (the activation that follows the BN; ReLU gradients are
  * already masked by the consumers, see engine.py). gamma/beta nullable (1/0). */

@@ -243,3 +243,28 @@ def test_per_sample_reductions_of_the_se_block(cfg, dtype, dev):
     ref_ds = (x.double() * dy.double()).sum(dim=(1, 2))
     assert float((avg.cpu().double() - ref_avg).abs().max()) < 1e-5 * max(1.0, float(ref_avg.abs().max())) + 1e-6
     assert float((ds.cpu().double() - ref_ds).abs().max()) < 2e-5 * float(ref_ds.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4096, 144), (23104, 576), (6400, 2304), (77, 40)])
+@pytest.mark.parametrize("act", [K.CS_ACT_NONE, K.CS_ACT_SILU, K.CS_ACT_RELU])
+def test_bn_apply_stats_equals_finalize_then_apply(shape, act):
+    """cs_bn_apply_stats (finalize folded into the apply pass) gives the bits of cs_bn_finalize + cs_bn_apply: y, the saved mean / rstd
+    and the running statistics."""
+    dev = torch.device("cuda:0")
+    M, C = shape
+    g = torch.Generator().manual_seed(M + C)
+    z = (torch.randn((M, C), generator=g) * 1.7 + 0.3).to(torch.bfloat16).to(dev)
+    res = torch.randn((M, C), generator=g).to(torch.bfloat16).to(dev) if act == K.CS_ACT_RELU else None
+    gamma = (torch.rand((C,), generator=g) + 0.5).to(dev)
+    beta = (torch.randn((C,), generator=g) * 0.1).to(dev)
+    stats = K.bn_stats(z)
+    rm0, rv0 = torch.randn((C,), generator=g).to(dev), (torch.rand((C,), generator=g) + 0.5).to(dev)
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    mean, rstd = K.bn_finalize(stats, M, 1e-3, 0.1, rm_a, rv_a)
+    y_ref = K.bn_apply(z, mean, rstd, gamma, beta, res, act)
+    y, mean2, rstd2 = K.bn_apply_stats(z, stats, 1e-3, 0.1, rm_b, rv_b, gamma, beta, res, act)
+    torch.cuda.synchronize()
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
