@@ -115,26 +115,27 @@ if "c4" in which:
         HF.cross_entropy(m(x, freeze_bn=True), y).backward()
         opt.step()
     run("c4 efficientnet_b3 tile bag=64 bf16 (fwd+bwd+Adam, BN train)", s4, 64, "tiles/s")
-    # roofline entry of C4's dominant kernel (profiles/round2_efficientnet_b3_kernel_stats.md: dw_wgrad_kernel): HIP events around every
-    # depthwise weight-gradient launch of three more steps; algorithmic bytes = x + dy once (+ the fp32 result), HBM-bound by
-    # construction (k*k*2 FLOP per 2-4 bytes)
+    # roofline entry of C4's dominant kernel family (profiles/round3_efficientnet_b3_kernel_stats.md: bn_bwd_reduce_kernel + bn_bwd_apply_kernel,
+    # 78 train-mode BatchNorms): HIP events around every BN backward of three more steps; algorithmic bytes = the reduction reads dy and z,
+    # the apply pass reads them again and writes dz: 5 passes over an M x C bf16 tensor; HBM-bound by construction
     from cellsegmentation_amd import kernels as KK
-    recs, orig = [], KK.dwconv_wgrad
+    recs, orig = [], KK.bn_bwd
 
-    def timed_dw(geom, xx, dyy):
+    def timed_bn(dy_, z_, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig(geom, xx, dyy)
+        out = orig(dy_, z_, *a, **k)
         e1.record()
-        recs.append((xx.numel() * xx.element_size() + dyy.numel() * dyy.element_size() + out.numel() * 4, e0, e1))
+        recs.append((5 * z_.numel() * z_.element_size(), e0, e1))
         return out
-    KK.dwconv_wgrad = timed_dw
+    KK.bn_bwd = timed_bn
     for _ in range(3):
         s4()
     torch.cuda.synchronize()
-    KK.dwconv_wgrad = orig
+    KK.bn_bwd = orig
     by, ms = sum(r[0] for r in recs), sum(r[1].elapsed_time(r[2]) for r in recs)
-    print(json.dumps({"config": "c4 roofline: dw_wgrad_kernel<bf16> + dw_wgrad_fold_kernel (26 launches/step, the largest row of the C4 profile)",
+    print(json.dumps({"config": "c4 roofline: bn_bwd_reduce_kernel + bn_partial_fold_kernel + bn_bwd_apply_kernel (78 BatchNorm backward passes/step, "
+                                "the largest rows of the C4 profile)",
                       "roofline": {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                    "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None},
                       "algorithmic_mbytes_per_step": round(by / 3 / 1e6, 1), "ms_per_step": round(ms / 3, 3), "launches_per_step": len(recs) // 3}),
