@@ -107,10 +107,13 @@ def main():
     out += [f"## C4: EfficientNet-B3 tile bag 64 bf16, BN train (GPU time {total:.2f} ms/step)", "",
             f"BatchNorm tensors of the 78 BN layers: {bn / 1e9:.2f} GB; depthwise inputs {dw_in / 1e9:.2f} GB, outputs {dw_out / 1e9:.2f} GB per pass.", "",
             "| kernel(s) | launches/step | ms/step | bound | algorithmic | achieved | frac | traffic |", "|---|---:|---:|---|---|---|---:|---|"]
-    spec = [("dw_wgrad_kernel<bf16>", r"^dw_wgrad_kernel", dw_in + dw_out), ("bn_bwd_reduce_kernel<bf16>", r"^bn_bwd_reduce", 2 * bn),
-            ("bn_bwd_apply_kernel<bf16>", r"^bn_bwd_apply", 3 * bn), ("bn_apply_kernel<bf16>", r"^bn_apply", 2 * bn),
-            ("dw_fwd_stats_kernel + dw_tile_kernel<..,STATS> (depthwise forward)", r"^dw_fwd_stats|^dw_tile_kernel<.*true,false>$", dw_in + dw_out),
-            ("dw_dgrad_kernel + dw_tile_kernel<..,FLIP> + dw_dgrad_s2_kernel", r"^dw_dgrad|^dw_tile_kernel<.*false,true>$", dw_in + dw_out),
+    spec = [("bn_bwd_reduce_kernel<bf16>", r"^bn_bwd_reduce", 2 * bn), ("bn_bwd_apply_kernel<bf16>", r"^bn_bwd_apply", 3 * bn),
+            ("bn_apply_kernel<bf16> (finalize folded in: cs_bn_apply_stats)", r"^bn_apply", 2 * bn),
+            ("dw_wgrad_strip_kernel<R,ST,TS> (depthwise weight gradient)", r"^dw_wgrad_strip_kernel|^dw_wgrad_kernel", dw_in + dw_out),
+            ("dw_conv_strip_kernel<..,STATS> (+ the one layer on dw_fwd_stats_kernel): depthwise forward + BN statistics",
+             r"^dw_conv_strip_kernel<.*true,false>$|^dw_fwd_stats|^dw_tile_kernel<.*true,false>$", dw_in + dw_out),
+            ("dw_conv_strip_kernel<..,FLIP> + dw_dgrad_s2_kernel: depthwise data gradient",
+             r"^dw_conv_strip_kernel<.*false,true>$|^dw_dgrad|^dw_tile_kernel<.*false,true>$", dw_in + dw_out),
             ("sample_rowsum_kernel (SE avg pool + ds)", r"^sample_rowsum_kernel", 3 * dw_out),
             ("se_scale_kernel + se_dx_kernel", r"^se_scale_kernel|^se_dx_kernel", 4 * dw_out)]
     for name, pat, by in spec:
@@ -138,30 +141,29 @@ def main():
         convs = [(2048, 1024, sizes[0]), (2048, 1024, sizes[0]), (1024, 512, sizes[1]), (1024, 512, sizes[1]), (512, 256, sizes[2]), (512, 256, sizes[2]),
                  (256, 128, sizes[3]), (128, 64, sizes[3])]
         fl = [2.0 * n * s * s * c * k * 9 for c, k, s in convs]
-        small = sum(fl[:6])               # served by the halo / wgrad2 kernels (image width <= 78 at 299; all but the last two)
-        big = sum(fl[6:])
+        tot = sum(fl)
+        # halo kernel: every forward but the last layer's (64 output channels: first generation) and every data gradient, the two widest
+        # layers on 8 x 16-pixel tiles; wgrad2: image widths <= 158 (all eight layers at 299, upconv1-6 at 512)
+        halo_fl = 2 * tot - fl[7]
+        w2_fl = tot if hw == 299 else sum(fl[:6])
         out += [f"## {title} (GPU time {total:.2f} ms/step)", "",
-                f"decoder 3x3 convolutions: {sum(fl) / 1e9:.0f} GFLOP forward per step ({small / 1e9:.0f} in upconv1-6, {big / 1e9:.0f} in the two widest layers).", "",
+                f"decoder 3x3 convolutions: {tot / 1e9:.0f} GFLOP forward per step ({sum(fl[6:]) / 1e9:.0f} of them in the two widest layers).", "",
                 "| kernel(s) | launches/step | ms/step | bound | algorithmic | achieved | frac | traffic |", "|---|---:|---:|---|---|---|---:|---|"]
         c, ms, tb = summed(tab, tr, r"^conv2_halo_kernel")
-        halo_ms = ms
-        if hw == 299:
-            out.append(line("conv2_halo_kernel<9,3,..> (upconv1-6 forward + data gradient)", c, ms, alg_tf=2 * small, traf=tb))
-            c, ms, tb = summed(tab, tr, r"^wgrad2_kernel")
-            out.append(line("wgrad2_kernel<..> (upconv1-6 weight gradient)", c, ms, alg_tf=small, traf=tb))
-        else:
-            out.append(line("conv2_halo_kernel<9,3,..>", c, ms, alg_tf=None, traf=tb))
-            c, ms, tb = summed(tab, tr, r"^wgrad2_kernel")
-            out.append(line("wgrad2_kernel<..>", c, ms, alg_tf=None, traf=tb))
+        # (the frozen encoder's stride-1 3x3 forwards run on the same kernel: 16 launches, ~0.16 of the forward FLOPs of a 299 x 299 image)
+        enc3 = 2.0 * n * 9 * sum(cc * cc * ss * ss * rep for cc, ss, rep in ((128, (hw + 7) // 8, 3), (256, (hw + 15) // 16, 5), (512, (hw + 31) // 32, 2)))
+        out.append(line("conv2_halo_kernel<9,3,..> (decoder forward + data gradient, the encoder's stride-1 3x3 forwards)", c, ms, alg_tf=halo_fl + enc3, traf=tb))
+        c, ms, tb = summed(tab, tr, r"^wgrad2_kernel")
+        out.append(line("wgrad2_kernel<..> (decoder weight gradients)", c, ms, alg_tf=w2_fl, traf=tb))
         c1, ms1, tb1 = summed(tab, tr, r"^igemm_dma_kernel<bf16,\d+,\d+,1,")
-        out.append(line("igemm_dma_kernel<..,1,..> (first generation: the widest decoder layers' fwd + dgrad, the encoder's strided 3x3)", c1, ms1, traf=tb1))
+        out.append(line("igemm_dma_kernel<..,1,..> (first generation: upconv8 forward, the encoder's three strided and three 64-channel 3x3)", c1, ms1, traf=tb1))
         c2, ms2, tb2 = summed(tab, tr, r"^wgrad_dma_kernel|^wgrad_spec_kernel")
         out.append(line("wgrad_dma / wgrad_spec (first generation weight gradients)", c2, ms2, traf=tb2))
         ch, msh, _ = summed(tab, tr, r"^conv2_halo_kernel")
         cw, msw, _ = summed(tab, tr, r"^wgrad2_kernel")
         fam_ms = msh + msw + ms1 + ms2
-        out += ["", f"decoder 3x3 family (all four rows, {3 * sum(fl) / 1e9:.0f} GFLOP fwd + dgrad + wgrad, the encoder's three strided 3x3 forwards included in the "
-                f"time): {3 * sum(fl) / (fam_ms * 1e-3) / 1e12:.0f} TFLOP/s = {3 * sum(fl) / (fam_ms * 1e-3) / 1e12 / PEAK_MFMA:.3f} of the dense bf16 peak.", ""]
+        out += ["", f"3x3 family (all four rows: {3 * sum(fl) / 1e9:.0f} GFLOP decoder fwd + dgrad + wgrad, {enc3 / 1e9:.0f} GFLOP encoder stride-1 forwards; the encoder's three strided 3x3 forwards only in the "
+                f"time): {(3 * sum(fl) + enc3) / (fam_ms * 1e-3) / 1e12:.0f} TFLOP/s = {(3 * sum(fl) + enc3) / (fam_ms * 1e-3) / 1e12 / PEAK_MFMA:.3f} of the dense bf16 peak.", ""]
         c, ms, tb = summed(tab, tr, r"^bn_apply|^bn_stats|^bn_bwd")
         out.append(f"BN passes (bn_stats / bn_apply / bn_bwd_*): {c:.0f} launches, {ms:.3f} ms/step, counter traffic {tb / 1e9:.2f} GB/step "
                    f"({tb / (ms * 1e-3) / 1e9:.0f} GB/s).")
