@@ -1387,7 +1387,7 @@ int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
     auto fn = conv2_halo_kernel<9, 3, TM, 1, 4, NBW, DG, T2D>;
     if (!allow_lds(fn, lds)) return CS_ERR_LAUNCH;
     char name[64];
-    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,%d,1,4,%d,%s%s>", TM, NBW, DG ? "true" : "false", T2D ? ",true" : "");
+    snprintf(name, sizeof(name), "conv2_halo_kernel<9,3,%d,1,4,%d,%s%s>", TM, NBW, DG ? "true" : "false", T2D ? ",true" : ",false");
     cs_set_variant_(name);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
@@ -1400,7 +1400,7 @@ int launch_halo(const C2Plan& pl, hipStream_t st) {
     if (pl.cfg == 2) {
         const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 256);
         dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
-        cs_set_variant_(DG ? "conv2_halo_kernel<9,3,4,2,2,8,true>" : "conv2_halo_kernel<9,3,4,2,2,8,false>");
+        cs_set_variant_(DG ? "conv2_halo_kernel<9,3,4,2,2,8,true,false>" : "conv2_halo_kernel<9,3,4,2,2,8,false,false>");
         if (!allow_lds(conv2_halo_kernel<9, 3, 4, 2, 2, 8, DG>, 8 * 8192 + EPI_LDS)) return CS_ERR_LAUNCH;
         hipLaunchKernelGGL((conv2_halo_kernel<9, 3, 4, 2, 2, 8, DG>), grid, dim3(256), 8 * 8192 + EPI_LDS, st, p);
         CS_LAUNCH_CHECK();
