@@ -243,6 +243,9 @@ def test_paired_stem_equals_the_generic_7x7_path(dev, dtype, hw):
     (256, 256, 3, 256, 5, 5),       # layer3 3x3 x5: 256-thread workgroups, two channel tiles
     (40, 24, 3, 24, 9, 2),          # odd sizes (Cin not a multiple of 4 is not served by the packed path, 24 is)
     (24, 6, 1, 8, 3, 1),            # Cin % 4 != 0: scalar tail of the 1x1 path
+    (1024, 256, 1, 256, 6, 6),      # layer3 256->1024 x6
+    (130, 96, 1, 96, 3, 2),         # K, Cin not multiples of 64
+    (66, 72, 3, 72, 2, 2),          # 3x3: a full and an 8-channel tile
 ])
 def test_wgrad_finalize_batched_matches_torch(K_, Cin, R, Cp, nsplit, n, dev):
     """cs_wgrad_finalize_batched (one launch per group of identical layers): dw[k][c][r][s] = scale[k] * sum over the split-K slabs,
@@ -276,6 +279,35 @@ def test_wgrad_finalize_batched_matches_torch(K_, Cin, R, Cp, nsplit, n, dev):
     for i in range(n):
         raw = slabs[i].double().sum(0)[..., :Cin].permute(0, 3, 1, 2)
         assert float((dws2[i].cpu().double() - raw).abs().max()) < 2e-5 * (1 + nsplit ** 0.5) * float(raw.abs().max())
+
+
+@pytest.mark.parametrize("K_,Cin,R,nsplit,n,rows", [(256, 64, 1, 64, 4, 2813), (1024, 256, 1, 6, 6, 181), (256, 256, 3, 5, 5, 241),
+                                                   (64, 64, 3, 126, 3, 5626), (130, 96, 1, 3, 2, 77)])
+def test_wgrad_finalize_batched_folds_partial_column_sums(K_, Cin, R, nsplit, n, rows, dev):
+    """The batched finalize takes the column sums of a data gradient as per-workgroup partial rows [rows][2][n_out] (first half of a
+    row) and folds them itself."""
+    torch.manual_seed(K_ + Cin + rows)
+    slabs = torch.randn(n, nsplit, K_, R, R, Cin)
+    ws = [torch.randn(K_, Cin, R, R) for _ in range(n)]
+    scales = [torch.rand(K_) + 0.5 for _ in range(n)]
+    rstds = [torch.rand(K_) + 0.5 for _ in range(n)]
+    means = [torch.randn(K_) for _ in range(n)]
+    n_out = (K_ + 7) // 8 * 8
+    parts = [torch.randn(rows, 2, n_out) for _ in range(n)]
+    d = lambda lst: [t.to(dev) for t in lst]
+    gs = [K.PartialColsum(p.to(dev), rows, n_out) for p in parts]
+    dws = [torch.empty((K_, Cin, R, R), device=dev) for _ in range(n)]
+    dgs = [torch.empty((K_,), device=dev) for _ in range(n)]
+    dbs = [torch.empty((K_,), device=dev) for _ in range(n)]
+    K.wgrad_finalize_batched(slabs.to(dev), d(ws), d(scales), d(rstds), d(means), gs, dws, dgs, dbs, Cin)
+    torch.cuda.synchronize()
+    for i in range(n):
+        gsum = parts[i][:, 0, :K_].double().sum(0)
+        raw = slabs[i].double().sum(0).permute(0, 3, 1, 2)
+        ref_dg = rstds[i].double() * ((ws[i].double() * raw).sum((1, 2, 3)) - means[i].double() * gsum)
+        tol = 2e-5 * (1 + nsplit ** 0.5)
+        assert float((dbs[i].cpu().double() - gsum).abs().max()) < 1e-5 * rows ** 0.5 * (1 + float(gsum.abs().max()))
+        assert float((dgs[i].cpu().double() - ref_dg).abs().max()) < tol * float(ref_dg.abs().max()) + 1e-3 * rows ** 0.5
 
 
 def test_wave_specialised_weight_gradient_on_every_shape(dev):
