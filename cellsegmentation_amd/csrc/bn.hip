@@ -86,12 +86,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, 
 
 // batch mean / 1/sqrt(var + eps) of one channel from its fp64 sums: ONE definition for cs_bn_finalize and for the apply pass that
 // derives them itself (cs_bn_apply_stats), so both give the same bits
+// (the sums and the mean / variance are fp64; 1/sqrt(var + eps) is formed in fp32 like ATen's batch_norm does for fp32 / bf16 inputs --
+// fp64 divisions and a fp64 square root per channel and THREAD cost the fused apply pass 3 us per launch)
 __device__ __forceinline__ void bn_moments(double s0, double s1, long long M, float eps, float& mean_f, float& rstd_f, double& var_out) {
-    const double mean = s0 / (double)M;
-    double var = s1 / (double)M - mean * mean;
+    const double inv_m = 1.0 / (double)M;
+    const double mean = s0 * inv_m;
+    double var = fma(s1, inv_m, -mean * mean);
     if (var < 0) var = 0;
     mean_f = (float)mean;
-    rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    rstd_f = 1.0f / sqrtf((float)var + eps);
     var_out = var;
 }
 __device__ __forceinline__ void bn_finalize_channel(const double* __restrict__ stats, int c, int C, long long M, float eps, float momentum,
