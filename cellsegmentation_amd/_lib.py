@@ -113,6 +113,7 @@ _SIGNATURES = {
     "cs_segmented_topk_workspace": (c_size_t, [c_longlong]),
     "cs_segmented_topk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_longlong, _P, _P, _P, c_size_t, _P]),
     "cs_stem_pair_input": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "cs_stem_pair_from_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "cs_stem_fwd_packed": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "cs_stem_pair_weights": (c_int, [_P, c_int, c_int, _P, _P]),
     "cs_stem_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),

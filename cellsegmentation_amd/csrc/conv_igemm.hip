@@ -2176,6 +2176,30 @@ __global__ __launch_bounds__(256) void stem_pair_input_kernel(const T* __restric
     }
 }
 
+// the same chunks straight from the fp32 NCHW image the drivers hand over (train_tile.py:264 `input.to(device)`): the NHWC8 intermediate
+// (91 MB written, 91 MB read per bag of 64 tiles) is never made.  Consecutive threads take consecutive pairs: 8 contiguous bytes per
+// thread and channel plane.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pair_from_nchw_kernel(const float* __restrict__ x, int N, int H, int W, int Wh, T* __restrict__ out) {
+    const long long total = (long long)N * H * Wh, plane = (long long)H * W;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % Wh);
+        const long long nh = idx / Wh;
+        const long long n = nh / H;
+        const int h = (int)(nh - n * H);
+        const float* src = x + (n * 3) * plane + (long long)h * W + 2 * j;
+        const bool two = 2 * j + 1 < W;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = src[c * plane];
+            v[4 + c] = two ? src[c * plane + 1] : 0.f;
+        }
+        v[3] = 0.f; v[7] = 0.f;
+        store8<T>(out + idx * 8, v);
+    }
+}
+
 template <typename T>
 __global__ void stem_pair_weights_kernel(const T* __restrict__ w /*[K][7][7][8]*/, int K, T* __restrict__ out /*[K][7][4][8]*/) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2221,6 +2245,19 @@ extern "C" int cs_stem_pair_input(const void* x_nhwc8, int dtype, int N, int H, 
     if (dtype == CS_F32) hipLaunchKernelGGL(stem_pair_input_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)x_nhwc8, N, H, W, Wh, (float*)x_pair);
     else if (dtype == CS_BF16) hipLaunchKernelGGL(stem_pair_input_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)x_nhwc8, N, H, W, Wh, (bf16_t*)x_pair);
     else CS_CHECK_ARG(false, "stem_pair_input: bad dtype");
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_stem_pair_from_nchw(const float* x_nchw, int dtype, int N, int H, int W, void* x_pair, void* stream) {
+    CS_CHECK_ARG(x_nchw && x_pair && N > 0 && H > 0 && W > 0, "stem_pair_from_nchw: bad arguments");
+    CS_CHECK_ARG(dtype == CS_BF16, "stem_pair_from_nchw: bf16 pairs only (the fp32 stem takes 4-channel NHWC pixels)");
+    const int Wh = (W + 1) / 2;
+    const long long total = (long long)N * H * Wh;
+    long long nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(stem_pair_from_nchw_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x_nchw, N, H, W, Wh,
+                       (bf16_t*)x_pair);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

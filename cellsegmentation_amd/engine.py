@@ -278,9 +278,29 @@ def _packed(st, geom, pkf, pkb):
     return st
 
 
-def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
-    """feeds: {slot: NHWC tensor}.  Returns state with .t (slot tensors) and .aux (per unit)."""
+def _stem_takes_nchw(plan, dtype):
+    """True when the plan's input feeds exactly one unit and that unit is the pixel-paired bf16 stem: the fp32 NCHW image can go
+    straight to the paired operand (cs_stem_pair_from_nchw) and the NHWC8 tensor is never made."""
+    if not (STEM_PAIRED and dtype == torch.bfloat16 and len(plan.inputs) == 1 and plan.units):
+        return False
+    u = plan.units[0]
+    if u.kind != "conv" or u.src != plan.inputs[0] or plan.consumers.get(u.src, 0) != 1 or u.grouped or u.res is not None:
+        return False
+    c = u.conv
+    return c.in_channels == 3 and c.kernel_size == (7, 7) and c.stride == (2, 2) and c.padding == (3, 3)
+
+
+def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_nchw=None):
+    """feeds: {slot: NHWC tensor}.  Returns state with .t (slot tensors) and .aux (per unit).
+    input_nchw: the network input as the contiguous fp32 [N,3,H,W] image instead (feeds then holds an UNINITIALISED placeholder of
+    the NHWC8 shape for that slot): converted here -- directly into the paired stem operand where the stem takes it."""
     t = dict(feeds)
+    nchw_for_stem = None
+    if input_nchw is not None:
+        if _stem_takes_nchw(plan, dtype):
+            nchw_for_stem = input_nchw
+        else:
+            t[plan.inputs[0]] = K.to_nhwc(input_nchw, dtype, K.pad_channels(3))
     aux = [None] * len(plan.units)
     remaining = dict(plan.consumers)
     in_hw = image_hw
@@ -357,7 +377,12 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None):
                     record.append((ui, conv, u.bn, Cp, Kp, need_bwd, pkf, pkb))
             # the stem runs on a pixel-paired image (kernels.stem_*): 28 instead of 49 K chunks
             stem = STEM_PAIRED and K.is_stem_geom(geom) and not u.grouped and res is None and conv.in_channels <= 3
-            xp = K.stem_pair_input(x) if stem else None
+            if ui == 0 and nchw_for_stem is not None:
+                if not stem:
+                    raise RuntimeError("engine: the stem was expected to take the NCHW image (placeholder input would be read)")
+                xp = K.stem_pair_from_nchw(nchw_for_stem, dtype)
+            else:
+                xp = K.stem_pair_input(x) if stem else None
             wp = K.stem_pair_weights(st.w_khwc) if stem else None
             if not batch_stats:
                 if stem and PACKED and K.stem_fwd_packed_supported(geom, dtype):
@@ -826,7 +851,7 @@ class _PlanFunction(torch.autograd.Function):
         param_needs = [ctx.needs_input_grad[3 + n_inputs + i] for i in range(len(params))]
         save = any(param_needs) or any(input_needs.values())
         requires, _ = compute_requires(plan, param_needs, input_needs)
-        state = forward(plan, feeds, cfg.dtype, cfg.bn_train, save, requires, cfg.image_hw)
+        state = forward(plan, feeds, cfg.dtype, cfg.bn_train, save, requires, cfg.image_hw, getattr(cfg, "input_nchw", None))
         ctx.plan, ctx.cfg, ctx.n_inputs = plan, cfg, n_inputs
         ctx.param_needs, ctx.requires = param_needs, requires
         ctx.state = state if save else None
@@ -845,8 +870,16 @@ class _PlanFunction(torch.autograd.Function):
         return (None, None, None) + tuple(in_grads[s] for s in plan.inputs) + tuple(pgrads)
 
 
-def run_plan(plan, inputs, dtype, bn_train, use_tr_read=True, image_hw=None):
+def run_plan(plan, inputs, dtype, bn_train, use_tr_read=True, image_hw=None, input_nchw=None):
     """Differentiable execution of a plan. inputs: NHWC tensors for plan.inputs; returns NHWC outputs.
-    image_hw: spatial size of the network input (for UpsampleUnit.size_fn)."""
-    cfg = SimpleNamespace(dtype=dtype, bn_train=bn_train, use_tr_read=use_tr_read, image_hw=image_hw)
+    image_hw: spatial size of the network input (for UpsampleUnit.size_fn).
+    input_nchw: a contiguous fp32 [N,3,H,W] image that does NOT require a gradient, given INSTEAD of the single NHWC input (inputs is
+    then ignored): the engine converts it itself, straight into the paired stem operand where the first unit is that stem."""
+    cfg = SimpleNamespace(dtype=dtype, bn_train=bn_train, use_tr_read=use_tr_read, image_hw=image_hw, input_nchw=None)
+    if input_nchw is not None:
+        if len(plan.inputs) != 1 or input_nchw.requires_grad or input_nchw.dtype != torch.float32 or input_nchw.dim() != 4 or input_nchw.shape[1] != 3:
+            raise ValueError("run_plan: input_nchw is a single fp32 [N,3,H,W] image without gradient")
+        cfg.input_nchw = input_nchw.contiguous()
+        N, _, H, W = input_nchw.shape
+        inputs = [torch.empty((N, H, W, K.pad_channels(3)), dtype=dtype, device=input_nchw.device)]      # shape carrier only (never read, never filled)
     return _PlanFunction.apply(plan, cfg, len(inputs), *inputs, *plan.param_tensors())

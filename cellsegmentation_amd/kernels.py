@@ -339,6 +339,16 @@ def stem_pair_input(x):
     return out
 
 
+def stem_pair_from_nchw(x_nchw, dtype):
+    """fp32 NCHW image [N,3,H,W] -> the paired stem operand [N,H,ceil(W/2),8] of `dtype` (bf16), without the NHWC8 intermediate."""
+    N, C, H, W = x_nchw.shape
+    if C != 3 or x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous():
+        raise ValueError("stem_pair_from_nchw expects a contiguous fp32 [N,3,H,W] image")
+    out = torch.empty((N, H, (W + 1) // 2, 8), dtype=dtype, device=x_nchw.device)
+    _lib.check(_lib.load().cs_stem_pair_from_nchw(_p(x_nchw), _code(dtype), N, H, W, _p(out), _stream()), "stem_pair_from_nchw")
+    return out
+
+
 def stem_pair_weights(w_khwc):
     """staged [K,7,7,8] -> paired [K,7,4,8]."""
     K_ = w_khwc.shape[0]

@@ -261,6 +261,9 @@ class MILResNet(nn.Module):
                                "move the model and its input to a cuda device")
         if x.dim() == 4 and x.shape[-1] == 8 and x.shape[1] != 3 and x.dtype == self.compute_dtype:
             xh = x                      # already staged NHWC tiles (cellsegmentation_amd.tiles.gather_tiles)
+        elif x.dim() == 4 and x.shape[1] == 3 and not x.requires_grad:
+            # the image as it comes from the loader: the engine converts it (straight into the paired stem operand for bf16)
+            return E.run_plan(self._encoder_plan(with_skips), [], self.compute_dtype, bn_train, self.use_tr_read, input_nchw=x.float())
         else:
             xh = HF.to_nhwc(x.float(), self.compute_dtype)
         return E.run_plan(self._encoder_plan(with_skips), [xh], self.compute_dtype, bn_train, self.use_tr_read)

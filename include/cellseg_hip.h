@@ -382,6 +382,8 @@ int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const void* w_pa
  *   cs_stem_wgrad       : raw split-K slabs dw_pair[cs_stem_wgrad_splits][K][7][4][8] from x_pair and dy
  *   cs_stem_unpair_slabs: those slabs summed into ONE ordinary raw slab dw_khwc[K][7][7][8] (input of cs_wgrad_finalize*) */
 int cs_stem_pair_input(const void* x_nhwc8, int dtype, int N, int H, int W, void* x_pair, void* stream);
+/* the same x_pair straight from the fp32 NCHW image [N][3][H][W] (cs_nchw_to_nhwc + cs_stem_pair_input in one pass; bf16 only) */
+int cs_stem_pair_from_nchw(const float* x_nchw, int dtype, int N, int H, int W, void* x_pair, void* stream);
 int cs_stem_pair_weights(const void* w_khwc, int dtype, int K, void* w_pair, void* stream);
 int cs_stem_fwd(int N, int H, int W, int K, int dtype, const void* x_pair, const void* w_pair, const float* scale, const float* shift,
                 int act, void* y, double* stats, void* workspace, void* stream);

@@ -310,3 +310,40 @@ def test_full_size_bag_properties_bf16(dev):
     # bf16 activations/gradients are rounded per tensor, so the two sides differ by rounding only where a sum is split differently
     # (weight-gradient slices, column sums): a few bf16 ulps relative to each tensor's largest entry
     assert worst < 2e-2, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("hw", [(64, 64), (75, 61)])
+def test_nchw_image_straight_into_the_stem(hw, dtype, dev):
+    """An fp32 NCHW image handed to the model goes to the engine as it is (run_plan(input_nchw=...)): for bf16 the paired stem operand is
+    made directly from it (cs_stem_pair_from_nchw, no NHWC8 intermediate), for fp32 the engine converts first.  Both must give the
+    bits of the explicit two-step staging (to_nhwc, then the plan): trunk output and the stem's weight gradient."""
+    from cellsegmentation_amd import engine as E
+    from cellsegmentation_amd import kernels as K
+    m = build("resnet18", dev, dtype)
+    m.setmode("tile")
+    m.set_encoder_grads(True)
+    m.eval()
+    torch.manual_seed(3)
+    x = torch.rand((3, 3, hw[0], hw[1]), device=dev) * 2 - 1
+    plan = m._encoder_plan(False)
+
+    def run(lazy):
+        m.zero_grad(set_to_none=True)
+        if lazy:
+            (y,) = E.run_plan(plan, [], dtype, False, m.use_tr_read, input_nchw=x)
+        else:
+            (y,) = E.run_plan(plan, [HF.to_nhwc(x, dtype)], dtype, False, m.use_tr_read)
+        y.float().square().mean().backward()
+        return y.detach().clone(), m.conv1.weight.grad.detach().clone()
+
+    ya, ga = run(False)
+    yb, gb = run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(ya.view(torch.int16 if dtype == torch.bfloat16 else torch.int32), yb.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+    assert torch.equal(ga, gb)
+    if dtype == torch.bfloat16:
+        # the direct kernel against the two-step operand
+        pa = K.stem_pair_input(K.to_nhwc(x, dtype, 8))
+        pb = K.stem_pair_from_nchw(x, dtype)
+        assert torch.equal(pa.view(torch.int16), pb.view(torch.int16))
