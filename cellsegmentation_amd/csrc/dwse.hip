@@ -3,8 +3,10 @@
 //   depthwise k x k convolution (k in {3,5}, stride in {1,2}), forward / data-grad / weight-grad
 //   squeeze-excitation channel scaling and its backward
 //   per-sample (row mode) stochastic-depth scale + residual add
-// All HBM-bound NHWC kernels, 8 channels (one 16-byte access for bf16) per thread; k*k*2 FLOP per
-// 2-4 bytes, so nothing here belongs on MFMA.
+// All HBM-bound NHWC kernels; k*k*2 FLOP per 2-4 bytes, so nothing here belongs on MFMA.  Three generations of depthwise kernels live
+// here: element-per-thread (8 channels = one 16-byte access per thread; fp32 and odd geometries), channel-tiled (round 3, first half:
+// the stride-2 data gradient per 2 x 2 block and one forward launch rule) and STRIPS (round 3, second half: bf16, k in {3, 5}, stride
+// in {1, 2}: forward + statistics, stride-1 data gradient, weight gradient) -- see the comments at each family.
 #include "cs_common.h"
 
 namespace {
