@@ -26,22 +26,20 @@ __device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const flo
         fold[1][threadIdx.x][e] = live ? b[e] : 0.f;
     }
     __syncthreads();
-    if ((int)threadIdx.x < width) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            double t0 = 0.0, t1 = 0.0;
-            for (int r = 0; r < rpar; ++r) {
-                t0 += (double)fold[0][r * width + threadIdx.x][e];
-                t1 += (double)fold[1][r * width + threadIdx.x][e];
-            }
-            if (partial) {
-                partial[(2LL * blockIdx.x) * C + cg * 8 + e] = t0;
-                partial[(2LL * blockIdx.x + 1) * C + cg * 8 + e] = t1;
-            } else {
-                atomicAdd(out0 + cg * 8 + e, t0);
-                atomicAdd(out1 + cg * 8 + e, t1);
-            }
-        }
+    // one thread per (sum, channel) COLUMN -- 2 * 8 * width of them: every lane folds rpar values.  (The first version let `width`
+    // threads fold 16 columns each: with 18 channel groups that is 18 lanes walking 224 dependent LDS reads, ~9 us at the end of every
+    // workgroup of a 26-us launch.)
+    const int cg0 = cg - (int)(threadIdx.x % width);
+    const int ncols = width * 8;
+    for (int col = threadIdx.x; col < 2 * ncols; col += 256) {
+        const int a_ = col >= ncols ? 1 : 0;
+        const int c_ = col - a_ * ncols;
+        const int cgl = c_ >> 3, e = c_ & 7;
+        double t = 0.0;
+        for (int r = 0; r < rpar; ++r) t += (double)fold[a_][r * width + cgl][e];
+        const int ch = (cg0 + cgl) * 8 + e;
+        if (partial) partial[(2LL * blockIdx.x + a_) * C + ch] = t;
+        else atomicAdd((a_ ? out1 : out0) + ch, t);
     }
 }
 
