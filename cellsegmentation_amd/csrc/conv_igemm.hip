@@ -306,17 +306,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 #pragma unroll
         for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
         __syncthreads();
-        if (tid < CG && ook) {
-            float t1[8], t2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-            for (int r = tid; r < 256; r += CG) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { t1[e] += red[r * 16 + e]; t2[e] += red[r * 16 + 8 + e]; }
+        // one thread per (sum, channel) column -- 16 * CG = 2 * BN of them -- folding its 256 / CG values in thread order (the same sums
+        // as when CG lanes walked 16 columns each: 8-16 lanes x 256-512 dependent LDS reads at the end of EVERY one-shot workgroup, on
+        // the train-mode-BN convolutions of EfficientNet and of the segmentation encoder)
+        float* row = p.slab + slab_row * 2 * p.NOUT;
+        for (int col = tid; col < CG * 16; col += 256) {
+            const int cgl = col >> 4, j = col & 15;
+            const int oc = n0 + cgl * 8;
+            if (oc < p.NOUT) {
+                float t = 0.f;
+                for (int r = cgl; r < 256; r += CG) t += red[r * 16 + j];
+                row[(j < 8 ? 0 : p.NOUT) + oc + (j & 7)] = t;
             }
-            float* row = p.slab + slab_row * 2 * p.NOUT;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { row[o + e] = t1[e]; row[p.NOUT + o + e] = t2[e]; }
         }
     }
 }

@@ -464,14 +464,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
 #pragma unroll
         for (int e = 0; e < 8; ++e) fold[threadIdx.x][e] = acc[e];
         __syncthreads();
-        if ((int)threadIdx.x < width) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = 0.f;
-                for (int r = 0; r < rpar; ++r) t += fold[r * width + threadIdx.x][e];
-                if constexpr (PARTIAL) out[(long long)blockIdx.x * 2 * C + cg * 8 + e] = t;
-                else atomicAdd(out + cg * 8 + e, t);
-            }
+        // one thread per channel column (8 * width of them), each folds rpar values in row order (the same sums as when `width` lanes
+        // walked 8 columns each -- 8 lanes x 256 dependent LDS reads at the end of every workgroup of a 64-channel tensor)
+        for (int col = threadIdx.x; col < width * 8; col += 256) {
+            const int cgl = col >> 3, e = col & 7;
+            float t = 0.f;
+            for (int r = 0; r < rpar; ++r) t += fold[r * width + cgl][e];
+            const int ch = (cg0 + cgl) * 8 + e;
+            if constexpr (PARTIAL) out[(long long)blockIdx.x * 2 * C + ch] = t;
+            else atomicAdd(out + ch, t);
         }
     }
 }
