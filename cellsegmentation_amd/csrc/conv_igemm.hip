@@ -902,8 +902,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     int r1 = r0 + per;
     if (r1 > rows) r1 = rows;
     double acc = 0.0;
-    if (c < ncols)
-        for (int r = r0 + rl; r < r1; r += 4) acc += (double)slab[(long long)r * stride + c];
+    if (c < ncols) {
+        // four rows in flight per thread (a single dependent load per step: up to 22 memory latencies per launch)
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            const float v0 = slab[(long long)r * stride + c], v1 = slab[(long long)(r + 4) * stride + c];
+            const float v2 = slab[(long long)(r + 8) * stride + c], v3 = slab[(long long)(r + 12) * stride + c];
+            a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+        }
+        for (; r < r1; r += 4) a0 += (double)slab[(long long)r * stride + c];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     __shared__ double red[4][64];
     red[rl][threadIdx.x & 63] = acc;
     __syncthreads();
