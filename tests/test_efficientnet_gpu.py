@@ -213,15 +213,17 @@ def test_stochastic_depth_row_mode_vs_oracle(dev):
 
 
 def test_depthwise_tiled_kernels_everywhere_the_geometry_allows(dev):
-    """The launch rule (csrc/dwse.hip: dw_tiled_geometry) sends only part of the 3x3 / 5x5 launches to the channel-tiled kernels;
-    CELLSEG_DW_UNTILED=2 forces them wherever the geometry allows, =1 forces the element-per-thread kernels.  Both extremes must
-    pass the same per-op parity test (the knob is read once per process: child interpreters)."""
+    """Three generations of depthwise kernels share the entry points: the strip kernels serve every bf16 3x3 / 5x5 launch, the launch
+    rule (csrc/dwse.hip: dw_tiled_geometry) sends part of what is left to the channel-tiled kernels, the rest goes to the
+    element-per-thread ones.  CELLSEG_DW_NOSTRIP=1 switches the strips off; CELLSEG_DW_UNTILED=2 then forces the tiled kernels wherever
+    the geometry allows, =1 the element-per-thread kernels.  Every combination must pass the same per-op parity test (the knobs are
+    read once per process: child interpreters)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("2", "1"):
-        env = dict(os.environ, CELLSEG_DW_UNTILED=mode)
+    for mode in ("2", "1", "0"):
+        env = dict(os.environ, CELLSEG_DW_UNTILED=mode, CELLSEG_DW_NOSTRIP="1")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_efficientnet_gpu.py"), "-m", "gpu", "-x", "-q",
                             "-k", "test_depthwise_conv"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
