@@ -224,9 +224,9 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
         for (int k = threadIdx.x; k < d.Kp; k += blockDim.x) {
             float r = 0.f, sc = 0.f, sh = 0.f;
             if (k < d.K) {
-                r = 1.0f / sqrtf(d.var[k] + d.eps);
+                r = d.var ? 1.0f / sqrtf(d.var[k] + d.eps) : 1.f;          // (var == NULL: a layer without a folded BatchNorm)
                 sc = (d.gamma ? d.gamma[k] : 1.f) * r;
-                sh = (d.beta ? d.beta[k] : 0.f) + ((d.conv_bias ? d.conv_bias[k] : 0.f) - d.mean[k]) * sc;
+                sh = (d.beta ? d.beta[k] : 0.f) + ((d.conv_bias ? d.conv_bias[k] : 0.f) - (d.mean ? d.mean[k] : 0.f)) * sc;
             }
             d.scale[k] = sc; d.shift[k] = sh; d.rstd[k] = r;
         }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
             }
             if (threadIdx.x < 16) {
                 const int k = k0 + threadIdx.x;
-                scl_s[threadIdx.x] = (d.gamma ? d.gamma[k] : 1.f) * (1.0f / sqrtf(d.var[k] + d.eps));
+                scl_s[threadIdx.x] = (d.gamma ? d.gamma[k] : 1.f) * (d.var ? 1.0f / sqrtf(d.var[k] + d.eps) : 1.f);
             }
             __syncthreads();
             if (w_khwc && !d.fwd_packed) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
             k = (int)(j % d.Kp); rs = (int)((j / d.Kp) % RS); c = (int)(j / ((long long)d.Kp * RS));
         }
         float v = 0.f;
-        if (k < d.K && c < d.Cin) v = d.w[((long long)k * d.Cin + c) * RS + rs] * ((d.gamma ? d.gamma[k] : 1.f) * (1.0f / sqrtf(d.var[k] + d.eps)));
+        if (k < d.K && c < d.Cin) v = d.w[((long long)k * d.Cin + c) * RS + rs] * ((d.gamma ? d.gamma[k] : 1.f) * (d.var ? 1.0f / sqrtf(d.var[k] + d.eps) : 1.f));
         if (first) w_khwc[j] = from_f32<T>(v);
         else w_chwk[j] = from_f32<T>(v);
     }

@@ -366,15 +366,17 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
             if save and any(p_ is not None and p_.requires_grad
                             for p_ in (conv.weight, conv.bias) + ((u.bn.weight, u.bn.bias) if (u.bn is not None and not batch_stats) else ())):
                 u._cache = None
-            if pre is not None and pre[0] == (Cp, Kp, need_bwd, pkf, pkb) and not batch_stats:
+            if pre is not None and pre[0] == (Cp, Kp, need_bwd, pkf, pkb, batch_stats):
                 st = pre[1]
             else:
                 if pre is not None:
                     packs.pop(dtype, None)          # the layout changed (other requires_grad pattern / geometry): rebuild next time
                 st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save, geom=geom, pkf=pkf, pkb=pkb)
-                if (record is not None and not batch_stats and u.bn is not None and not u.grouped
-                        and any(p_ is not None and p_.requires_grad for p_ in (conv.weight, conv.bias, u.bn.weight, u.bn.bias))):
-                    record.append((ui, conv, u.bn, Cp, Kp, need_bwd, pkf, pkb))
+                # (a batch-statistics layer joins the one-launch staging with bn = None: its operands depend on the convolution only)
+                if (record is not None and not u.grouped and (batch_stats or u.bn is not None)
+                        and any(p_ is not None and p_.requires_grad
+                                for p_ in (conv.weight, conv.bias) + (() if batch_stats else (u.bn.weight, u.bn.bias)))):
+                    record.append((ui, conv, None if batch_stats else u.bn, Cp, Kp, need_bwd, pkf, pkb))
             # the stem runs on a pixel-paired image (kernels.stem_*): 28 instead of 49 K chunks
             stem = STEM_PAIRED and K.is_stem_geom(geom) and not u.grouped and res is None and conv.in_channels <= 3
             if ui == 0 and nchw_for_stem is not None:
@@ -481,9 +483,12 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
     if record:
         pk = K.StagePack([r_[1:] for r_ in record], dtype)
         pk.by_unit = {}
-        for (ui_, _, _, cp_, kp_, nb_, pkf_, pkb_), (w_khwc, w_chwk, scale, shift, rstd) in zip(record, pk.staged):
-            pk.by_unit[ui_] = ((cp_, kp_, nb_, pkf_, pkb_), SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd,
-                                                                             fwd_packed=bool(pkf_), bwd_packed=bool(pkb_ and nb_)))
+        for (ui_, _, bn_, cp_, kp_, nb_, pkf_, pkb_), (w_khwc, w_chwk, scale, shift, rstd) in zip(record, pk.staged):
+            if bn_ is None:                          # batch statistics: the consumers expect no folded scale (and no rstd)
+                scale = rstd = None
+            pk.by_unit[ui_] = ((cp_, kp_, nb_, pkf_, pkb_, bn_ is None),
+                               SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd,
+                                               fwd_packed=bool(pkf_), bwd_packed=bool(pkb_ and nb_)))
         packs[dtype] = pk
     return SimpleNamespace(t=t, aux=aux, in_hw=in_hw, bits=bits)
 

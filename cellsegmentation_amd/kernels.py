@@ -92,9 +92,10 @@ def stage_conv_bn(w, gamma, beta, mean, var, eps, conv_bias, dtype, Cp, Kp, want
 
 
 class StagePack:
-    """Every eval-mode Conv2d+BatchNorm2d of a network staged by ONE launch (cs_stage_conv_bn_multi).
+    """Every Conv2d(+eval-mode BatchNorm2d) of a network staged by ONE launch (cs_stage_conv_bn_multi).
 
-    layers: [(conv, bn, Cp, Kp, want_bwd, fwd_packed, bwd_packed)].  The staging buffers and the device descriptor table are
+    layers: [(conv, bn, Cp, Kp, want_bwd, fwd_packed, bwd_packed)]; bn = None for a layer whose BatchNorm runs on batch statistics
+    (scale 1, shift = the convolution's bias or 0).  The staging buffers and the device descriptor table are
     allocated once and rewritten by every launch(); valid() tells whether the parameter tensors are still the ones the table
     points at.  *_packed: the operand is written in the MFMA-fragment order of the packed-operand kernels (conv_v2.hip)."""
 
@@ -110,12 +111,16 @@ class StagePack:
             w_chwk = torch.empty((Cp, R, S, Kp), dtype=dtype, device=dev) if want_bwd else None
             vec = torch.empty((3, Kp), dtype=torch.float32, device=dev)
             d = arr[i]
-            d.w, d.gamma, d.beta = conv.weight.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
-            d.mean, d.var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            d.w = conv.weight.data_ptr()
+            if bn is not None:
+                d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                d.mean, d.var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            else:                                   # a layer whose BatchNorm runs on batch statistics: nothing of it is folded
+                d.gamma = d.beta = d.mean = d.var = None
             d.conv_bias = conv.bias.data_ptr() if conv.bias is not None else None
             d.w_khwc, d.w_chwk = w_khwc.data_ptr(), (w_chwk.data_ptr() if want_bwd else None)
             d.scale, d.shift, d.rstd = vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr()
-            d.eps = float(bn.eps)
+            d.eps = float(bn.eps) if bn is not None else 0.0
             d.K, d.Cin, d.R, d.S, d.Cp, d.Kp, d.block0 = K_, Cin, R, S, Cp, Kp, block
             d.fwd_packed, d.bwd_packed = int(bool(pkf)), int(bool(pkb and want_bwd))
             if (pkf and (Kp % 32 or Cp % 64)) or (pkb and want_bwd and (Cp % 32 or Kp % 64)):
@@ -132,7 +137,7 @@ class StagePack:
     def _key(self):
         out = []
         for conv, bn, *_ in self.layers:
-            for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var):
+            for t in (conv.weight, conv.bias) + ((bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else ()):
                 out.append(t.data_ptr() if t is not None else 0)
         return tuple(out)
 

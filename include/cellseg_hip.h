@@ -112,7 +112,8 @@ int cs_stage_conv_bn(const float* w, const float* gamma, const float* beta, cons
  * by the host for a fixed set of parameter / staging buffers; block0 = prefix sum of cs_stage_conv_bn_blocks() over the layers,
  * total_blocks = the sum. */
 typedef struct CsStageDesc {
-    const float *w, *gamma, *beta, *mean, *var, *conv_bias;   /* gamma / beta / conv_bias nullable */
+    const float *w, *gamma, *beta, *mean, *var, *conv_bias;   /* gamma / beta / conv_bias nullable; mean == var == NULL: no BatchNorm is folded
+                                                                 * (train-mode BN layers: scale = 1, shift = conv_bias or 0) */
     void *w_khwc, *w_chwk;                                     /* either nullable */
     float *scale, *shift, *rstd;                               /* [Kp] */
     float eps;
