@@ -512,9 +512,16 @@ def _geom_key(geom):
 
 
 def _defers(u, a, need, ui):
-    """Eval-BN, ungrouped, bias-free convolutions whose weight AND BN gradients are wanted take the batched path."""
-    return (u.kind == "conv" and need(ui, "weight") and (need(ui, "gamma") or need(ui, "beta")) and not need(ui, "bias")
-            and not a.train and not u.grouped and u.bn is not None and u.conv.bias is None)
+    """Ungrouped, bias-free convolutions take the batched weight-gradient path: eval-BN layers whose weight AND BN gradients are wanted
+    (the finalize also writes dgamma / dbeta), and batch-statistics layers whose weight gradient is wanted (their BN gradients come
+    from the BN backward pass; the finalize only folds the slabs)."""
+    if not (u.kind == "conv" and need(ui, "weight") and not need(ui, "bias") and not u.grouped and u.bn is not None and u.conv.bias is None):
+        return False
+    return True if a.train else bool(need(ui, "gamma") or need(ui, "beta"))
+
+
+def _group_key(geom, a):
+    return (_geom_key(geom), bool(a.train))
 
 
 PACKED_TRAIN_BN = os.environ.get("CELLSEG_PACKED_TRAIN_BN", "1") != "0"   # ... also for heavy 3x3 convolutions under batch-statistics BN
@@ -608,7 +615,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
     group_total = {}
     for ui_, u_ in enumerate(plan.units):
         if ui_ in need_w_units and aux[ui_] is not None and _defers(u_, aux[ui_], need, ui_):
-            k_ = _geom_key(aux[ui_].geom)
+            k_ = _group_key(aux[ui_].geom, aux[ui_])
             group_total[k_] = group_total.get(k_, 0) + 1
     group_seen = {}
 
@@ -629,14 +636,20 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         n = len(items)
         convs = [it.u.conv for it in items]
         Cin = convs[0].in_channels
+        train = bool(items[0].a.train)                   # (a group is all eval-BN or all batch-statistics: _group_key)
         dws = [grad_buffer(c.weight) for c in convs]
-        dgs = [grad_buffer(it.u.bn.weight) for it in items]
-        dbs = [grad_buffer(it.u.bn.bias) for it in items]
+        dgs = None if train else [grad_buffer(it.u.bn.weight) for it in items]
+        dbs = None if train else [grad_buffer(it.u.bn.bias) for it in items]
         # (single layers take the same path: its finalize folds deferred column sums, the stand-alone one does not)
         if n == 1 and items[0].a.xp is not None:
             slabs = K.stem_wgrad(geom, items[0].a.xp, items[0].dz, use_tr_read=use_tr_read).unsqueeze(0)     # [1, 1, K, 7, 7, 8]
         else:
             slabs = K.wgrad_batched(geom, [it.x for it in items], [it.dz for it in items], use_tr_read=use_tr_read)
+        if train:
+            K.wgrad_finalize_batched(slabs, None, None, None, None, None, dws, None, None, Cin)
+            for it, dw in zip(items, dws):
+                emit(it.ui, "weight", dw)
+            return
         K.wgrad_finalize_batched(slabs, [c.weight.detach() for c in convs], [it.a.st.scale for it in items],
                                  [it.a.st.rstd for it in items], [it.u.bn.running_mean for it in items], [it.gsum for it in items],
                                  dws, dgs, dbs, Cin)
@@ -688,12 +701,14 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             if _defers(u, a, need, ui):
                 # weight gradients of identical-geometry layers are launched together (one batched split-K launch per shape
                 # group: proportionally fewer partial slabs to write and fold)
-                gsum = gsum_cache.pop(u.dst, None)
-                if gsum is None:
-                    gsum = K.colsum_partial(dz)
-                if u.res is not None and grads.get(u.res) is g:
-                    gsum_cache[u.res] = gsum
-                key = _geom_key(geom)
+                gsum = None
+                if not a.train:
+                    gsum = gsum_cache.pop(u.dst, None)
+                    if gsum is None:
+                        gsum = K.colsum_partial(dz)
+                    if u.res is not None and grads.get(u.res) is g:
+                        gsum_cache[u.res] = gsum
+                key = _group_key(geom, a)
                 items = deferred.setdefault(key, [])
                 items.append(SimpleNamespace(ui=ui, u=u, a=a, x=x, dz=dz, gsum=gsum))
                 group_seen[key] = group_seen.get(key, 0) + 1
