@@ -40,6 +40,9 @@ struct IgemmParams {
     const unsigned char* bits_in;
     float* slab;      // nullable fp32 [M tiles][2][NOUT]: per-workgroup column sums / sums of squares of the
                       // stored output (no atomics; cs_slab_reduce folds the rows afterwards)
+    double* stat_atomic;   // with slab != NULL: add the workgroup's sums to this fp64 [2][NOUT] instead of storing its partial row (launches
+                           // with few pixel tiles: <= 512 atomics per address, and the slab_reduce launch -- one per train-mode-BN convolution,
+                           // 20-53 per step on the ResNet-18 counter / EfficientNet-B3 / the segmentation encoder -- disappears)
     int SH, SW, SC;   // source extents, stored channels
     int DH, DW;       // destination spatial extents
     int NOUT;         // destination channels
@@ -316,7 +319,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
             if (oc < p.NOUT) {
                 float t = 0.f;
                 for (int r = cgl; r < 256; r += CG) t += red[r * 16 + j];
-                row[(j < 8 ? 0 : p.NOUT) + oc + (j & 7)] = t;
+                const int o_ = (j < 8 ? 0 : p.NOUT) + oc + (j & 7);
+                if (p.stat_atomic) atomicAdd(p.stat_atomic + o_, (double)t);
+                else row[o_] = t;
             }
         }
     }
@@ -1067,9 +1072,16 @@ int igemm_tile(long long M, int NOUT) {
 }
 
 template <typename T>
-int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream_t st) {
+int dispatch_igemm(const IgemmParams& p_in, float* colsum, double* stats, hipStream_t st) {
     int rc;
+    IgemmParams p = p_in;
     int tile = igemm_tile(p.M, p.NOUT);
+    {
+        // train-mode BN statistics of a launch with few pixel tiles: fp64 atomics from the epilogue, no fold launch
+        static const int atomic_rows = cs_env_int_("CELLSEG_STATS_ATOMIC_ROWS", 512);      // A/B experiments only (1 = never)
+        const long long rows_ = (p.M + tile / 1000 - 1) / (tile / 1000);
+        if (p.slab && stats && !colsum && !p.cslab && !p.ncls && rows_ <= atomic_rows) p.stat_atomic = stats;
+    }
     if (p.cslab) tile = (p.M + 127) / 128 >= 384 ? 128064 : 64064;   // one 64-channel slab per N tile
     switch (tile) {
         case 128128: rc = launch_igemm<T, 128, 128>(p, st); break;
@@ -1077,7 +1089,7 @@ int dispatch_igemm(const IgemmParams& p, float* colsum, double* stats, hipStream
         case 128064: rc = launch_igemm<T, 128, 64>(p, st); break;
         default: rc = launch_igemm<T, 64, 64>(p, st); break;
     }
-    if (rc != CS_OK || !p.slab || (!colsum && !stats)) return rc;      // no colsum/stats target: the partial rows are the result
+    if (rc != CS_OK || !p.slab || (!colsum && !stats) || p.stat_atomic) return rc;      // no colsum/stats target: the partial rows are the result
     const int bm = tile / 1000;
     int rows = (int)((p.M + bm - 1) / bm);
     if (p.ncls) {
