@@ -350,6 +350,10 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __re
     if (rl == 0 && j < cols && b0 < blocks) atomicAdd(out + j, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
+// Up to this many workgroups a reduction adds its per-workgroup sums with fp64 atomics (<= 512 per address) instead of writing partial
+// rows for a second launch to fold: one launch less per small BatchNorm (the folds themselves already end in fp64 atomics).
+constexpr int kBnAtomicBlocks = 512;
+
 inline int fold_partial(const double* partial, int blocks, int C, double* out, hipStream_t st) {
     int chunks = blocks / 16;
     if (chunks < 1) chunks = 1;
@@ -407,6 +411,7 @@ extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double*
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rpb = rows_per_block_for(M, C);
     const int blocks = (int)((M + rpb - 1) / rpb);
+    if (blocks <= kBnAtomicBlocks) workspace = nullptr;      // few workgroups: fp64 atomics straight into `stats`, no fold launch
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, M, C, stats, rpb, workspace),
                   hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, M, C, stats, rpb, workspace),
@@ -471,6 +476,7 @@ extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rpb = rows_per_block_for(M, C);
     const int blocks = (int)((M + rpb - 1) / rpb);
+    if (blocks <= kBnAtomicBlocks) workspace = nullptr;      // (as in cs_bn_stats)
     CS_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
                                      rstd, gamma, beta, act, M, C, sums, rpb, workspace),
