@@ -53,7 +53,8 @@ def main():
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"# {title}\n")
-    print(f"`rocprofv3 --kernel-trace --stats`, {steps} steps in the run (warm-up included); GPU time {tot / 1e6 / steps:.3f} ms/step\n")
+    print(f"`rocprofv3 --kernel-trace --stats`, {steps} steps in the run (warm-up included); GPU time {tot / 1e6 / steps:.3f} ms/step "
+          f"(the run's set-up -- parameter upload: `__amd_rocclr_copyBuffer`, fills -- is averaged over the steps too; no copy runs inside a step)\n")
     print("| kernel | calls/step | avg us | ms/step | % |")
     print("|---|---:|---:|---:|---:|")
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:30]:
