@@ -43,10 +43,9 @@ __device__ __forceinline__ float lin_act_grad(float g, float yv, int act) {
 
 // dx[m][k] = sum_n g[m][n] w[n][k]: one wave per output, lanes stride over n (N reaches 2304 in the SE blocks: a
 // thread-per-output loop was a 2304-long serial chain on a 24-workgroup grid)
-__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                        const float* __restrict__ w, float* __restrict__ dx, int M, int N,
-                                                        int K, int act) {
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void linear_dx_body(unsigned block, const float* __restrict__ dy, const float* __restrict__ y,
+                                               const float* __restrict__ w, float* __restrict__ dx, int M, int N, int K, int act) {
+    const long long wave = ((long long)block * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= (long long)M * K) return;
     const int m = (int)(wave / K), k = (int)(wave % K);
@@ -58,13 +57,17 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
     acc = wave_sum(acc);
     if (lane == 0) dx[wave] = acc;
 }
+__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ w, float* __restrict__ dx, int M, int N,
+                                                        int K, int act) {
+    linear_dx_body(blockIdx.x, dy, y, w, dx, M, N, K, act);
+}
 
 // dw[n][k] = sum_m g[m][n] x[m][k];  db[n] = sum_m g[m][n] (k == 0 thread)
-__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                        const float* __restrict__ x, float* __restrict__ dw,
-                                                        float* __restrict__ db, int M, int N, int K, int act,
-                                                        int accumulate) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void linear_dw_body(unsigned block, const float* __restrict__ dy, const float* __restrict__ y,
+                                               const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int M, int N,
+                                               int K, int act, int accumulate) {
+    const long long idx = (long long)block * 256 + threadIdx.x;
     if (idx >= (long long)N * K) return;
     const int n = (int)(idx / K), k = (int)(idx % K);
     float acc = 0.f, accb = 0.f;
@@ -77,6 +80,12 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     dw[idx] = accumulate ? dw[idx] + acc : acc;
     if (db && k == 0) db[n] = accumulate ? db[n] + accb : accb;
 }
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ x, float* __restrict__ dw,
+                                                        float* __restrict__ db, int M, int N, int K, int act,
+                                                        int accumulate) {
+    linear_dw_body(blockIdx.x, dy, y, x, dw, db, M, N, K, act, accumulate);
+}
 
 // ---- Round 3: the three Linear products as 64 x 64 LDS tiles (4 x 4 outputs per thread).  The one-output-per-thread / per-wave
 // kernels above cost 9-28 us per call on the squeeze-excitation layers of EfficientNet-B3 (53 calls of each per step, 2.6 ms): the
@@ -87,14 +96,12 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 // with g = dy * act'(y).  Both operands sit in LDS "contraction-major" ([l][64 + 1]) so the inner loop is two conflict-free
 // 16-byte reads per 16 multiply-adds.
 template <int MODE>
-__global__ __launch_bounds__(256) void linear_tiled_kernel(const float* __restrict__ a0, const float* __restrict__ a1, const float* __restrict__ b0,
-                                                           const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ out2,
-                                                           int M, int N, int K, int act, int accumulate) {
-    __shared__ __attribute__((aligned(16))) float At[64][68];
-    __shared__ __attribute__((aligned(16))) float Bt[64][68];
+__device__ __forceinline__ void linear_tile_body(float (*At)[68], float (*Bt)[68], unsigned bx, unsigned by, const float* __restrict__ a0,
+                                                 const float* __restrict__ a1, const float* __restrict__ b0, const float* __restrict__ bias,
+                                                 float* __restrict__ out, float* __restrict__ out2, int M, int N, int K, int act, int accumulate) {
     // I x J outputs, contraction length L
     const int I = MODE == 2 ? N : M, J = MODE == 0 ? N : K, L = MODE == 0 ? K : (MODE == 1 ? N : M);
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int i0 = (int)bx * 64, j0 = (int)by * 64;
     const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4;
     float acc[4][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -159,8 +166,37 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const float* __restri
             }
         }
         if constexpr (MODE == 2) {
-            if (out2 && blockIdx.y == 0 && tj == 0) out2[i] = accumulate ? out2[i] + accb[u] : accb[u];
+            if (out2 && by == 0 && tj == 0) out2[i] = accumulate ? out2[i] + accb[u] : accb[u];
         }
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void linear_tiled_kernel(const float* __restrict__ a0, const float* __restrict__ a1, const float* __restrict__ b0,
+                                                           const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ out2,
+                                                           int M, int N, int K, int act, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float At[64][68];
+    __shared__ __attribute__((aligned(16))) float Bt[64][68];
+    linear_tile_body<MODE>(At, Bt, blockIdx.x, blockIdx.y, a0, a1, b0, bias, out, out2, M, N, K, act, accumulate);
+}
+
+// dx and dw of one Linear in ONE launch: the two products are independent, but as two launches they ran one after the other -- two chains
+// of latencies on a handful of workgroups each (the squeeze-excitation layers of EfficientNet: 104 such launches, 10-15 us each, per
+// step).  Workgroups [0, nx) compute dx, the rest dw; each side keeps its own kernel shape (64 x 64 tiles or one wave / thread per output).
+template <bool DXT, bool DWT>
+__global__ __launch_bounds__(256) void linear_bwd_dual_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                              const float* __restrict__ y, float* __restrict__ dx, float* __restrict__ dw,
+                                                              float* __restrict__ db, int M, int N, int K, int act, int accumulate, unsigned nx,
+                                                              unsigned dx_gx, unsigned dw_gx) {
+    __shared__ __attribute__((aligned(16))) float At[(DXT || DWT) ? 64 : 1][68];
+    __shared__ __attribute__((aligned(16))) float Bt[(DXT || DWT) ? 64 : 1][68];
+    unsigned b = blockIdx.x;
+    if (b < nx) {
+        if constexpr (DXT) linear_tile_body<1>(At, Bt, b % dx_gx, b / dx_gx, dy, y, w, nullptr, dx, nullptr, M, N, K, act, 0);
+        else linear_dx_body(b, dy, y, w, dx, M, N, K, act);
+    } else {
+        b -= nx;
+        if constexpr (DWT) linear_tile_body<2>(At, Bt, b % dw_gx, b / dw_gx, dy, y, x, nullptr, dw, db, M, N, K, act, accumulate);
+        else linear_dw_body(b, dy, y, x, dw, db, M, N, K, act, accumulate);
     }
 }
 
@@ -352,6 +388,23 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
     CS_CHECK_ARG(dy && M > 0 && N > 0 && K > 0, "linear_bwd: bad arguments");
     CS_CHECK_ARG(act == CS_ACT_NONE || y, "linear_bwd: an output activation needs y (SiLU: the pre-activation)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dx && dw) {
+        CS_CHECK_ARG(w && x, "linear_bwd: dx needs w, dw needs x");
+        const bool dxt = (long long)M * K >= 1024 && lin_use_tiles(M, K, N), dwt = (long long)N * K >= 1024 && lin_use_tiles(N, K, M);
+        const unsigned dx_gx = (unsigned)((M + 63) / 64), dw_gx = (unsigned)((N + 63) / 64), gy = (unsigned)((K + 63) / 64);
+        const unsigned nx = dxt ? dx_gx * gy : (unsigned)(((long long)M * K + 3) / 4);
+        const unsigned nw = dwt ? dw_gx * gy : (unsigned)(((long long)N * K + 255) / 256);
+#define CS_LIN_DUAL(A_, B_)                                                                                                            \
+    hipLaunchKernelGGL((linear_bwd_dual_kernel<A_, B_>), dim3(nx + nw), dim3(256), 0, st, x, w, dy, y, dx, dw, db, M, N, K, act, accumulate, nx, \
+                       dx_gx, dw_gx)
+        if (dxt && dwt) CS_LIN_DUAL(true, true);
+        else if (dxt) CS_LIN_DUAL(true, false);
+        else if (dwt) CS_LIN_DUAL(false, true);
+        else CS_LIN_DUAL(false, false);
+#undef CS_LIN_DUAL
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dx) {
         CS_CHECK_ARG(w, "linear_bwd: dx needs w");
         const long long waves = (long long)M * K;
