@@ -1162,37 +1162,22 @@ static void dw_wgrad_split(const CsConvGeom* g, int& rows_per_block, unsigned& n
     nslab = (unsigned)((rows + rpb - 1) / rpb);
 }
 
-// strip kernel: strip length (the one of the two instantiated per stride that wastes fewer columns), items per workgroup, partial rows
-static bool dw_strip_serves(const CsConvGeom* g, int dtype) {
-    static const int off = cs_env_int_("CELLSEG_DW_NOSTRIP", 0);      // A/B experiments only
-    const long long xb = (long long)g->N * g->H * g->W * g->C * 2, yb = (long long)g->N * g->P * g->Q * g->C * 2;
-    return !off && dtype == CS_BF16 && (g->R == 3 || g->R == 5) && (g->stride == 1 || g->stride == 2) && xb < (1ll << 30) && yb < (1ll << 30);
-}
-static void dw_strip_split(const CsConvGeom* g, int& ts, int& per, unsigned& nblk, int& chunks, int& cpt) {
-    const int a = g->stride == 1 ? 8 : 4, b = 5;
-    const int wa = (g->Q + a - 1) / a * a, wb = (g->Q + b - 1) / b * b;
-    ts = wb < wa ? b : a;
-    dw_strip_shape(g->C, chunks, cpt);
-    const long long items = (long long)g->N * g->P * ((g->Q + ts - 1) / ts);
-    long long blocks = 4096 / chunks;                    // 16 workgroups per CU in all: a workgroup's item count varies with its edge strips
-    if (blocks < 1) blocks = 1;
-    long long cap = (32ll << 20) / ((long long)g->R * g->R * g->C * 4);      // partial rows: at most 32 MiB, at least 128 rows
+// strip weight gradient: the same planning as the strip convolutions (dw_strip_plan); partial rows: at most 32 MiB, at least 128 rows
+static DwStrip dw_strip_plan_wgrad(const CsConvGeom* g) {
+    long long cap = (32ll << 20) / ((long long)g->R * g->R * g->C * 4);
     if (cap < 128) cap = 128;
-    if (blocks > cap) blocks = cap;
-    long long p_ = (items + blocks - 1) / blocks;
-    const int npl = 256 / cpt;
-    if (p_ < 2 * npl) p_ = 2 * npl;
-    per = (int)p_;
-    nblk = (unsigned)((items + p_ - 1) / p_);
+    return dw_strip_plan(g->N, g->P, g->Q, g->C, g->stride, 4096, cap);
+}
+static bool dw_strip_wgrad_ok(const CsConvGeom* g, int dtype) {
+    return dw_strip_ok(g->R, g->stride, (long long)g->N * g->H * g->W * g->C, (long long)g->N * g->P * g->Q * g->C, dtype);
 }
 
 extern "C" size_t cs_dwconv_wgrad_workspace(const CsConvGeom* g) {
     if (!g || check_dw(g, "dwconv_wgrad_workspace: bad geometry")) return 0;
     int rpb; unsigned nslab;
     dw_wgrad_split(g, rpb, nslab);
-    if (g->R == 3 || g->R == 5) {                        // (either kernel may serve the call: room for both)
-        int ts, per, chunks, cpt; unsigned nblk;
-        dw_strip_split(g, ts, per, nblk, chunks, cpt);
+    if ((g->R == 3 || g->R == 5) && (g->stride == 1 || g->stride == 2)) {      // (either kernel may serve the call: room for both)
+        const unsigned nblk = dw_strip_plan_wgrad(g).nblk;
         if (nblk > nslab) nslab = nblk;
     }
     return (size_t)nslab * g->R * g->R * g->C * sizeof(float);
@@ -1205,9 +1190,10 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
     CS_CHECK_ARG(dtype == CS_F32 || dtype == CS_BF16, "dwconv_wgrad: bad dtype");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int ncols = g->R * g->R * g->C;
-    if (dw_strip_serves(g, dtype)) {
-        int ts, per, sch, cpt; unsigned nblk;
-        dw_strip_split(g, ts, per, nblk, sch, cpt);
+    if (dw_strip_wgrad_ok(g, dtype)) {
+        const DwStrip d_ = dw_strip_plan_wgrad(g);
+        const int ts = d_.ts, per = d_.per, sch = d_.chunks, cpt = d_.cpt;
+        const unsigned nblk = d_.nblk;
         const unsigned xb = (unsigned)((long long)g->N * g->H * g->W * g->C * 2), yb = (unsigned)((long long)g->N * g->P * g->Q * g->C * 2);
 #define CS_DW_STRIP(R_, S_, T_)                                                                                                          \
     hipLaunchKernelGGL((dw_wgrad_strip_kernel<R_, S_, T_>), dim3(nblk, (unsigned)sch), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, \
