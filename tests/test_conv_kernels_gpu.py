@@ -344,3 +344,22 @@ def test_weight_prep_tiled_layouts(shape, dev):
         ref_c[:Cin, :, :, :Kc] = ws.permute(1, 2, 3, 0).to(torch.bfloat16)
         assert torch.equal(wk.cpu().view(Kp, R, R, Cp), ref_k)
         assert torch.equal(wc.cpu().view(Cp, R, R, Kp), ref_c)
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 19, 64, 128, 1), (8, 38, 38, 128, 144, 1), (64, 38, 38, 32, 192, 1), (3, 21, 17, 64, 64, 3)])
+def test_conv_fwd_batch_statistics_atomic_and_slab_paths(shape, dev):
+    """cs_conv2d_fwd with `stats`: per-channel sum / sum of squares of the STORED bf16 output.  Launches with <= 512 pixel tiles add them
+    with fp64 atomics from the epilogue, larger ones leave partial rows for slab_reduce (the third shape: 722 tiles); both must match the
+    sums of the stored tensor."""
+    N, H, W, Cin, Cout, R = shape
+    g_ = torch.Generator().manual_seed(H + Cin + Cout)
+    x = torch.randn((N, H, W, Cin), generator=g_).to(torch.bfloat16).to(dev)
+    w = (torch.randn((Cout, Cin, R, R), generator=g_) / (Cin * R * R) ** 0.5).to(dev)
+    geom = K.make_geom(N, H, W, Cin, Cout, R, R, 1, R // 2)
+    wk, _ = K.weight_prep(w, None, torch.bfloat16, Cin, Cout, True, False)
+    stats = K.new_stats(Cout, dev)
+    y = K.conv_fwd(geom, x, wk, None, None, None, K.CS_ACT_NONE, stats=stats)
+    torch.cuda.synchronize()
+    yd = y.double().view(-1, Cout)
+    assert torch.allclose(stats[0].cpu(), yd.sum(0).cpu(), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(stats[1].cpu(), (yd * yd).sum(0).cpu(), rtol=1e-6, atol=1e-4)
