@@ -36,18 +36,25 @@ class Adam(torch.optim.Optimizer):
 
     def _plan(self, gi, plist):
         lib = _lib.load()
-        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in plist)
+        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel(),
+                     self.state[p]["step"].data_ptr()) for p in plist)
         cached = self._plans.get(gi)
         if cached is not None and cached[0] == key:
             return cached
         dev = plist[0].device
         chunk, cap = lib.cs_adam_chunk_elems(), lib.cs_adam_max_tensors()
-        table = torch.tensor([[k[0], k[1], k[2], k[3]] for k in key], dtype=torch.int64).to(dev)          # CsAdamTensor[]
+        table = torch.tensor([[k[0], k[1], k[2], k[3]] for k in key], dtype=torch.int64).to(dev)          # CsAdamTensor[] (p, m, v, n)
         launches = []
         for t0 in range(0, len(plist), cap):
             sub = plist[t0:t0 + cap]
             ch = [(t0 + i, c) for i, p in enumerate(sub) for c in range((p.numel() + chunk - 1) // chunk)]
-            launches.append((t0, len(sub), torch.tensor(ch, dtype=torch.int32).to(dev), len(ch)))
+            by_step = {float(self.state[p]["step"]) for p in sub}
+            if len(by_step) != 1:
+                raise RuntimeError("cellsegmentation_amd.optim.Adam: parameters of one launch are at different step counts "
+                                   "(a parameter skipped earlier steps); use torch.optim.Adam for such schedules")
+            # [t0, n, chunk table, n_chunks, step count so far (host copy: the per-parameter `step` tensors are advanced with one
+            #  foreach add per step, not read back), the step tensors]
+            launches.append([t0, len(sub), torch.tensor(ch, dtype=torch.int32).to(dev), len(ch), by_step.pop(), [self.state[p]["step"] for p in sub]])
         self._plans[gi] = (key, table, launches)
         return self._plans[gi]
 
@@ -69,19 +76,14 @@ class Adam(torch.optim.Optimizer):
             beta1, beta2 = group["betas"]
             _, table, launches = self._plan(gi, plist)
             stream = torch.cuda.current_stream(plist[0].device).cuda_stream
-            for t0, n, chunks, n_chunks in launches:
+            for ln in launches:
+                t0, n, chunks, n_chunks = ln[0], ln[1], ln[2], ln[3]
                 sub = plist[t0:t0 + n]
-                by_step = {}
-                for p in sub:
-                    by_step.setdefault(float(self.state[p]["step"]), []).append(p)
-                if len(by_step) != 1:
-                    raise RuntimeError("cellsegmentation_amd.optim.Adam: parameters of one launch are at different step counts "
-                                       "(a parameter skipped earlier steps); use torch.optim.Adam for such schedules")
-                t = next(iter(by_step)) + 1.0
+                t = ln[4] + 1.0
                 gts = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in sub]       # (kept alive until the launch is queued)
                 grads = (ctypes.c_void_p * n)(*[g.data_ptr() for g in gts])
                 _lib.check(lib.cs_adam_step(table.data_ptr(), grads, t0, n, chunks.data_ptr(), n_chunks, float(group["lr"]), float(beta1),
                                             float(beta2), float(group["eps"]), float(group["weight_decay"]), t, stream), "adam_step")
-            for p in plist:
-                self.state[p]["step"] += 1
+                ln[4] = t
+                torch._foreach_add_(ln[5], 1.0)
         return loss

@@ -73,7 +73,7 @@ if "c1" in which:
     # the same step replayed as one HIP graph (cellsegmentation_amd.graphed): the eager step is host-bound (~1000 launches)
     from cellsegmentation_amd.graphed import GraphedStep
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
-    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=8e-5, weight_decay=1e-4, capturable=True)
+    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=8e-5, weight_decay=1e-4, capturable=True, fused=FUSED)
 
     def s1g_body(xb, cb, nb):
         optg.zero_grad(set_to_none=True)
