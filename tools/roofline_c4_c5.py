@@ -47,6 +47,7 @@ def b3_tensors(N=64):
     H, cin = 150, adj(32)
     bn = N * H * H * cin * 2
     dw_in = dw_out = 0
+    pw = 0                                   # 1x1 convolutions: input + output bytes of one forward pass (expand: e != 1, project, head)
     for (e, k, s, ci, co, l) in base:
         co, l = adj(co), int(math.ceil(l * 1.4))
         for i in range(l):
@@ -58,9 +59,17 @@ def b3_tensors(N=64):
             bn += N * Ho * Ho * ce * 2 + N * Ho * Ho * co * 2
             dw_in += N * H * H * ce * 2
             dw_out += N * Ho * Ho * ce * 2
+            if e != 1:
+                pw += N * H * H * (cin + ce) * 2
+            pw += N * Ho * Ho * (ce + co) * 2
             H, cin = Ho, co
     bn += N * H * H * cin * 4 * 2
-    return bn, dw_in, dw_out
+    pw += N * H * H * (cin + 4 * cin) * 2
+    return bn, dw_in, dw_out, pw
+
+
+def find_ms(tab, pat):
+    return sum(v[1] for k, v in tab.items() if re.search(pat, k)) or 1e-9
 
 
 def find(tab, pat):
@@ -102,7 +111,7 @@ def main():
     tab = stats(os.path.join(ROOT, "gpurun_out", "round", "prof_c4", "p_kernel_stats.csv"), 12) if os.path.exists(
         os.path.join(ROOT, "gpurun_out", "round", "prof_c4", "p_kernel_stats.csv")) else {}
     tr = traffic(os.path.join(P, "round3_traffic_c4.json"))
-    bn, dw_in, dw_out = b3_tensors()
+    bn, dw_in, dw_out, pw = b3_tensors()
     total = sum(v[1] for v in tab.values())
     out += [f"## C4: EfficientNet-B3 tile bag 64 bf16, BN train (GPU time {total:.2f} ms/step)", "",
             f"BatchNorm tensors of the 78 BN layers: {bn / 1e9:.2f} GB; depthwise inputs {dw_in / 1e9:.2f} GB, outputs {dw_out / 1e9:.2f} GB per pass.", "",
@@ -121,12 +130,13 @@ def main():
         if ms:
             out.append(line(name, c, ms, alg_gb=by, traf=tb))
     c, ms, tb = summed(tab, tr, r"^igemm_dma_kernel|^igemm_kernel")
-    # 1x1 convolutions of B3: 1.666 GMAC forward per tile -> forward + data gradient
-    out.append(line("igemm_dma_kernel<..> (1x1 expand / project / head, fwd + dgrad)", c, ms, alg_tf=2 * 2 * 1.666e9 * 64, traf=tb))
+    # 1x1 convolutions of B3 (1.666 GMAC forward per tile; 24-384 channels on one side: 20-190 FLOP/B): HBM-bound by construction --
+    # algorithmic bytes = input + output of the forward, dy + dx of the data gradient, x + dy of the weight gradient
+    out.append(line("igemm_dma_kernel<..> (1x1 expand / project / head, fwd + dgrad; the stem's 3x3 included in the time)", c, ms, alg_gb=2 * pw, traf=tb))
     c, ms, tb = summed(tab, tr, r"^wgrad_dma_kernel|^wgrad_spec_kernel|^wgrad_kernel")
-    out.append(line("wgrad_dma / wgrad_spec (1x1 weight gradients)", c, ms, alg_tf=2 * 1.666e9 * 64, traf=tb))
-    out += ["", "(the 1x1 products of an MBConv have 24-384 channels on one side: 20-190 FLOP/B, HBM-bound by construction; they are priced "
-            "against MFMA here only to show how far from a matrix-core problem they are)", ""]
+    out.append(line("wgrad_dma / wgrad_spec (1x1 weight gradients)", c, ms, alg_gb=pw, traf=tb))
+    out += ["", f"(1x1 products: {2 * 2 * 1.666e9 * 64 / 1e9:.0f} GFLOP fwd + dgrad per step = "
+            f"{2 * 2 * 1.666e9 * 64 / (find_ms(tab, r'^igemm_dma_kernel|^igemm_kernel') * 1e-3) / 1e12:.0f} TFLOP/s: not a matrix-core problem)", ""]
     # ---------------- C5
     for tag, csvname, trname, n, hw, title in (("c5", "prof_c5", "round3_traffic_c5.json", 8, 299, "C5: ResNet-50 segmentation B=8 299x299 bf16 (decoder training)"),
                                               ("c5x", "prof_c5x", "round3_traffic_c5x.json", 4, 512, "C5: the same at 512x512 B=4")):
