@@ -1064,7 +1064,12 @@ int igemm_tile(long long M, int NOUT) {
     if (forced) return (NOUT <= 64 && forced % 1000 == 128) ? forced - 64 : forced;
     static const int thr = cs_env_int_("CELLSEG_TILE_THR", 1536);   // experiments only (A/B: 384..3072 within 1 %, 1536 best)
     const long long mt128 = (M + 127) / 128;
-    if (NOUT > 64) {
+    // 64-wide tiles where they cut the padded width by a fifth or more (144 or 192 output channels: 192 instead of 256 columns): the
+    // EfficientNet expansions at 150 x 150 / 75 x 75 ran their second 128-wide N tile 12 % / 50 % full -- and a workgroup's epilogue costs
+    // the same however full its tile is (24 -> 144 @150x150: 244 us at 128 wide)
+    static const int narrow = cs_env_int_("CELLSEG_TILE_NARROW", 1);      // A/B experiments only (2 = off)
+    const int p128 = (NOUT + 127) / 128 * 128, p64 = (NOUT + 63) / 64 * 64;
+    if (NOUT > 64 && !(narrow == 1 && p64 * 5 <= p128 * 4)) {
         const long long blocks = mt128 * ((NOUT + 127) / 128);
         return blocks >= thr ? 128128 : 64128;
     }

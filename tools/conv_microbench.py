@@ -33,6 +33,13 @@ SHAPES = {
     "l3_3x3_s2": (64, 38, 38, 256, 256, 3, 2, 1),
     "l4_3x3_s2": (64, 19, 19, 512, 512, 3, 2, 1),
     "dec_3x3_2048_1024": (8, 19, 19, 2048, 1024, 3, 1, 1),
+    # EfficientNet-B3 1x1 products (expand / project): HBM-bound, odd channel counts
+    "eff_exp_24_144_150": (64, 150, 150, 24, 144, 1, 1, 0),
+    "eff_prj_144_32_75": (64, 75, 75, 144, 32, 1, 1, 0),
+    "eff_exp_32_192_75": (64, 75, 75, 32, 192, 1, 1, 0),
+    "eff_prj_288_96_19": (64, 19, 19, 288, 96, 1, 1, 0),
+    "eff_exp_96_576_19": (64, 19, 19, 96, 576, 1, 1, 0),
+    "eff_exp_232_1392_10": (64, 10, 10, 232, 1392, 1, 1, 0),
 }
 
 
