@@ -358,6 +358,56 @@ def fp32_parity_mode_rate(dev, x, labels, steps=5, warmup=2):
             "note": "fp32 activations + v_mfma_f32_32x32x2_f32 (first-generation kernels); the mode of the 1e-4 parity tests"}
 
 
+def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
+    """N = 1 only, outside the timed region: the same step with the gradient exchange switched ON over a one-rank RCCL
+    communicator (`GradReducer(force_collectives=True)`: 32 MB flat buckets all-reduced from inside the HIP backward on a side
+    stream).  A world of one moves no bytes over xGMI, so what this prices is everything else the N > 1 path adds to a step: the
+    RCCL kernel launches, the side-stream hand-offs and the 1/world scaling pass.  Never `value`."""
+    import socket
+    import torch.distributed as dist
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    red = GradReducer(params, force_collectives=True).attach()
+    red.broadcast_parameters(model)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = HF.cross_entropy(model(x, freeze_bn=True), labels, 1.0)
+        loss.backward()
+        red.reduce()
+        opt.step()
+
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        early = red.launches_in_backward
+        red.time_collectives = True
+        step()
+        times = red.collective_times()
+    finally:
+        red.detach()
+        if own_pg:
+            dist.destroy_process_group()
+    return {"ms_per_step_with_collectives": round(dt * 1e3, 3), "tiles_per_s": round(BAG / dt, 1), "steps": steps,
+            "buckets": len(red.buckets), "buckets_sent_inside_backward": early,
+            "allreduce_ms_per_step": round(sum(t for _, t in times), 4),
+            "per_bucket": [{"mbytes": round(n / 1e6, 2), "ms": round(t, 4)} for n, t in times],
+            "note": "one-rank RCCL communicator (backend nccl): all-reduce + 1/world scale per bucket, event-timed on the side stream"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,6 +419,7 @@ def main():
     ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32 parity-mode side number (N=1, bf16 runs)")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
     ap.add_argument("--event-every", type=int, default=5, help="HIP-event-bracket the conv launches of every Nth timed step (1 = all)")
+    ap.add_argument("--no-rccl-side", action="store_true", help="skip the one-rank RCCL side run (N=1)")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-geometry launch table to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
@@ -406,9 +457,8 @@ def main():
     if reducer is not None:
         reducer.broadcast_parameters(model)
 
-    # synthetic IHC tiles: a few distinct ones per rank, tiled to the bag (inputs resident in HBM)
-    base = synth.normalise(synth.ihc_tiles(8, SIZE, 1234 + rank))
-    x = base.repeat(BAG // 8, 1, 1, 1).contiguous().to(dev)
+    # synthetic IHC tiles: 64 distinct ones per rank (inputs resident in HBM)
+    x = synth.normalise(synth.ihc_tiles(BAG, SIZE, 1234 + rank)).contiguous().to(dev)
     labels = torch.tensor([(i * 7 + 1) % 2 for i in range(BAG)], device=dev)
     loss_acc = torch.zeros((), device=dev)
 
@@ -463,6 +513,12 @@ def main():
             roof["event_timed_steps"] = timed_steps
         if timer is not None and args.per_layer:
             print(per_layer_table(timer.results(), timed_steps, dtype), file=sys.stderr)
+        rccl_side = None
+        if world == 1 and not args.no_rccl_side:
+            try:
+                rccl_side = rccl_world1_side(dev, model, params, opt, x, labels)
+            except Exception as e:  # noqa: BLE001 -- a side number must never take the headline line down
+                rccl_side = {"error": f"{type(e).__name__}: {e}"[:300]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -488,6 +544,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "fp32_parity_mode": fp32_side,
+            "rccl_world1": rccl_side,
         }
         print(json.dumps(out))
     if world > 1:

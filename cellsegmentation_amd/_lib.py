@@ -8,10 +8,16 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcellseg_hip.so")
+# CELLSEG_LIB_FLAVOUR=ab: the A/B build (`make AB=1`: launch-rule knobs read from CELLSEG_* and cs_set_igemm_path compiled in).
+# Only the forced-mode tests and the tools/ sweeps set it, in child processes; the product loads the production library.
+FLAVOUR = os.environ.get("CELLSEG_LIB_FLAVOUR", "")
+if FLAVOUR not in ("", "ab"):
+    raise RuntimeError(f"CELLSEG_LIB_FLAVOUR={FLAVOUR!r}: expected unset or 'ab'")
+LIB_PATH = os.path.join(_HERE, "libcellseg_hip_ab.so" if FLAVOUR == "ab" else "libcellseg_hip.so")
 
 CS_F32, CS_BF16 = 0, 1
 CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU, CS_ACT_SIGMOID = 0, 1, 2, 3
+CS_BN_BWD_OWN_RELU, CS_BN_BWD_FROZEN = 0x100, 0x200       # flags OR-ed into `act` of cs_bn_bwd_reduce / cs_bn_bwd_apply
 
 
 class CsConvGeom(Structure):
@@ -29,6 +35,10 @@ class CellsegLibraryMissing(RuntimeError):
 
 
 _P = c_void_p
+# entry points that exist in the A/B flavour only (include/cellseg_hip.h: #ifdef CS_AB_SWITCHES)
+_AB_SIGNATURES = {
+    "cs_set_igemm_path": (c_int, [c_int]),
+}
 _SIGNATURES = {
     # name: (restype, argtypes)
     "cs_abi_version": (c_int, []),
@@ -44,7 +54,6 @@ _SIGNATURES = {
     "cs_conv2d_fwd": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "cs_conv2d_stats_workspace": (c_size_t, [c_longlong, c_int]),
     "cs_igemm_tile": (c_int, [c_longlong, c_int]),
-    "cs_set_igemm_path": (c_int, [c_int]),
     "cs_conv2d_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cs_conv2d_fwd_bits": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "cs_conv2d_dgrad_bits": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -153,6 +162,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, intentionally fatal
         fn.restype = restype
         fn.argtypes = argtypes
+    if FLAVOUR == "ab":
+        for name, (restype, argtypes) in _AB_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
     _lib = lib
     return lib
 

@@ -201,7 +201,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
 // eight elements at once with ONE branch on the activation: a branch per element makes every exp -> add -> rcp chain its own basic
 // block, and the eight chains run back to back instead of interleaved
 __device__ __forceinline__ void act_grad8(float (&g)[8], const float (&xh)[8], const float (&gm)[8], const float (&bt)[8], int act) {
-    if (act != CS_ACT_SILU) return;
+    if (act & CS_BN_BWD_OWN_RELU) {
+        // the ReLU that follows THIS normalisation with nothing in between (BatchNorm1d -> ReLU of the image heads, resnet.py:134-136):
+        // the mask is the sign of the layer's own output, recomputed in the forward's operation order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (xh[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
+    }
+    if ((act & 0xff) != CS_ACT_SILU) return;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float u = gm[e] * xh[e] + bt[e];
@@ -293,10 +299,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         load8p(rstd + cg * 8, 1.f, rs);
         load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
         load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
+        const bool frozen = (act & CS_BN_BWD_FROZEN) != 0;      // running statistics: mean / rstd do not depend on the batch
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            k0[e] = (float)sums[cg * 8 + e] * invM;
-            k1[e] = (float)sums[C + cg * 8 + e] * invM;
+            k0[e] = frozen ? 0.f : (float)sums[cg * 8 + e] * invM;
+            k1[e] = frozen ? 0.f : (float)sums[C + cg * 8 + e] * invM;
             gr[e] = gm[e] * rs[e];
         }
         auto finish = [&](float (&g)[8], const float (&zz)[8], const long long off) {

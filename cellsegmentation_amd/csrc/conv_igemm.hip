@@ -943,9 +943,9 @@ void note_variant(const char* fmt, ...) {
 
 int g_stream_enabled = 0;   // persistent streaming kernel for short-K pure-GEMM convs: opt-in (cs_set_igemm_path(3)); measured
                             // 5-25 % SLOWER than the one-shot kernel on MI355X (its vmcnt(0) also drains the previous tile's stores)
-const bool g_merge_classes = [] { const char* e = getenv("CELLSEG_NO_MERGE"); return !(e && atoi(e)); }();   // A/B experiments only
-const bool g_uni_walk = [] { const char* e = getenv("CELLSEG_NO_UNI"); return !(e && atoi(e)); }();   // A/B experiments only
-const bool g_epi_prefetch = [] { const char* e = getenv("CELLSEG_NO_EPI_PREFETCH"); return !(e && atoi(e)); }();   // A/B experiments only
+const bool g_merge_classes = !cs_env_flag_("CELLSEG_NO_MERGE");   // A/B experiments only
+const bool g_uni_walk = !cs_env_flag_("CELLSEG_NO_UNI");   // A/B experiments only
+const bool g_epi_prefetch = !cs_env_flag_("CELLSEG_NO_EPI_PREFETCH");   // A/B experiments only
 int g_igemm_path = 0;   // 0 = LDS-DMA when operands < 2 GiB, 1 = always register-staged (A/B testing)
 
 int igemm_mode(const IgemmParams& p) {
@@ -1127,6 +1127,7 @@ int check_geom(const CsConvGeom* g, int dtype) {
 }  // namespace
 
 extern "C" int cs_igemm_tile(long long M, int n_out) { return igemm_tile(M, n_out); }
+#ifdef CS_AB_SWITCHES
 extern "C" int cs_set_igemm_path(int path) {
     // 0 = LDS-DMA (default), 1 = register-staged everywhere, 3 = LDS-DMA + persistent streaming kernel for short-K 1x1
     const int old = g_igemm_path == 1 ? 1 : (g_stream_enabled ? 3 : 0);
@@ -1134,6 +1135,7 @@ extern "C" int cs_set_igemm_path(int path) {
     g_stream_enabled = path == 3 ? 1 : 0;
     return old;
 }
+#endif
 
 extern "C" size_t cs_conv2d_stats_workspace(long long M, int n_out) {
     // one partial row per M tile; sized for the smallest tile height (64) so every dispatch variant fits
@@ -2039,7 +2041,7 @@ int wgrad_splits(long long M, int KO, int QE, int BM, int n_items = 1) {
 }
 
 const int g_wgrad_nst = cs_env_int_("CELLSEG_WGRAD_NST", 3);   // A/B experiments only
-const bool g_wgrad_dma = [] { const char* e = getenv("CELLSEG_WGRAD_REG"); return !(e && atoi(e)); }();   // A/B experiments only
+const bool g_wgrad_dma = !cs_env_flag_("CELLSEG_WGRAD_REG");   // A/B experiments only
 
 template <typename T, int BM, int BN, bool TR>
 int launch_wgrad(WgradParams p, hipStream_t st, int n_items = 1) {

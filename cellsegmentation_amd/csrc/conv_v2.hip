@@ -1181,7 +1181,7 @@ int pick_tm(long long M, int n_ntiles) {
     return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
 }
 
-const bool g_v2_off = [] { const char* e = getenv("CELLSEG_NO_V2"); return e && atoi(e); }();
+const bool g_v2_off = cs_env_flag_("CELLSEG_NO_V2");     // A/B flavour only
 
 bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;

@@ -142,7 +142,11 @@ static inline int cs_ceil_div(long long a, long long b) { return (int)((a + b - 
 // at the call).  cs_api.cpp keeps the (device, function) table under a mutex; `limit` is the byte count to allow (<= 160 KiB).
 extern "C" int cs_allow_dynamic_lds_(const void* fn, size_t bytes, size_t limit);
 
-// A/B knobs read from the environment: a positive integer, anything else (unset, 0, negative, non-numeric) -> `dflt`.
+// A/B knobs.  The production library (`make`) has none: every knob is its default, nothing reads the environment and
+// cs_set_igemm_path is not exported.  `make AB=1` (-DCS_AB_SWITCHES -> libcellseg_hip_ab.so, loaded by the forced-mode tests and
+// the tools/ sweeps through CELLSEG_LIB_FLAVOUR=ab) reads them: a positive integer, anything else (unset, 0, negative,
+// non-numeric) -> `dflt`.
+#ifdef CS_AB_SWITCHES
 static inline int cs_env_int_(const char* name, int dflt) {
     const char* e = getenv(name);
     if (!e || !*e) return dflt;
@@ -151,3 +155,8 @@ static inline int cs_env_int_(const char* name, int dflt) {
     if (end == e || v <= 0 || v > (1 << 24)) return dflt;
     return (int)v;
 }
+#else
+static inline int cs_env_int_(const char*, int dflt) { return dflt; }
+#endif
+// "<NAME>=<positive integer>" set (A/B flavour only)
+static inline bool cs_env_flag_(const char* name) { return cs_env_int_(name, 0) != 0; }

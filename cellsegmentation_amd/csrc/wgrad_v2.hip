@@ -218,7 +218,7 @@ void magic(unsigned d, unsigned& mg, unsigned& sh) {
 
 struct W2Plan { int bl, xr; W2Params p; };
 
-const bool g_wgrad2_off = [] { const char* e = getenv("CELLSEG_NO_WGRAD2"); return e && atoi(e); }();     // A/B experiments only
+const bool g_wgrad2_off = cs_env_flag_("CELLSEG_NO_WGRAD2");     // A/B experiments only
 
 bool plan(const CsConvGeom* g, int dtype, int n_items, W2Plan& pl) {
     if (g_wgrad2_off || !g || dtype != CS_BF16) return false;

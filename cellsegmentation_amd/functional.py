@@ -92,17 +92,15 @@ class _BatchNormRows(torch.autograd.Function):
         stats = K.bn_stats(x)
         mean, rstd = K.bn_finalize(stats, M, eps, momentum, running_mean, running_var)
         y = K.bn_apply(x, mean, rstd, gamma.detach(), beta.detach(), None, act)
-        ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.act = act
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, mean, rstd, gamma = ctx.saved_tensors
-        g = g.contiguous()
-        if ctx.act == K.CS_ACT_RELU:
-            g = g * (y > 0)
-        dz, dgamma, dbeta = K.bn_bwd(g, x, mean, rstd, gamma.detach())
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        flags = K.CS_BN_BWD_OWN_RELU if ctx.act == K.CS_ACT_RELU else 0       # the ReLU mask is applied inside the HIP passes
+        dz, dgamma, dbeta = K.bn_bwd(g.contiguous(), x, mean, rstd, gamma.detach(), beta=beta.detach(), act=flags)
         return dz, dgamma, dbeta, None, None, None, None, None
 
 
@@ -114,18 +112,18 @@ class _AffineRows(torch.autograd.Function):
         x = x.contiguous()
         _, _, rstd = K.bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
         y = K.bn_apply(x, running_mean, rstd, gamma.detach(), beta.detach(), None, act)
-        ctx.save_for_backward(x, y, rstd, gamma, running_mean)
+        ctx.save_for_backward(x, rstd, gamma, beta, running_mean)
         ctx.act = act
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, rstd, gamma, mean = ctx.saved_tensors
-        if ctx.act == K.CS_ACT_RELU:
-            g = g * (y > 0)
-        s = (gamma * rstd).unsqueeze(0)
-        xhat = (x - mean.unsqueeze(0)) * rstd.unsqueeze(0)
-        return g * s, (g * xhat).sum(0), g.sum(0), None, None, None, None
+        x, rstd, gamma, beta, mean = ctx.saved_tensors
+        # dz = gamma * rstd * g, dgamma = sum g * xhat, dbeta = sum g (g masked by the layer's own ReLU): the train-mode passes with
+        # the batch terms switched off
+        flags = K.CS_BN_BWD_FROZEN | (K.CS_BN_BWD_OWN_RELU if ctx.act == K.CS_ACT_RELU else 0)
+        dz, dgamma, dbeta = K.bn_bwd(g.contiguous(), x, mean, rstd, gamma.detach(), beta=beta.detach(), act=flags)
+        return dz, dgamma, dbeta, None, None, None, None
 
 
 def batch_norm_rows(x, bn, act=K.CS_ACT_NONE):

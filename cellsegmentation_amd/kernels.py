@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SIGMOID, CS_ACT_SILU, CS_BF16, CS_F32, CsConvGeom  # noqa: F401
+from ._lib import (CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SIGMOID, CS_ACT_SILU, CS_BF16, CS_BN_BWD_FROZEN, CS_BN_BWD_OWN_RELU, CS_F32,  # noqa: F401
+                   CsConvGeom)
 
 
 def _code(dtype):
@@ -206,7 +207,10 @@ def _stats_ws(M, n_out, device):
 
 
 def set_igemm_path(path):
-    """0 = LDS-DMA staging (default), 1 = register staging, 3 = LDS-DMA + experimental streaming kernel. Returns the previous value."""
+    """0 = LDS-DMA staging (default), 1 = register staging, 3 = LDS-DMA + experimental streaming kernel. Returns the previous value.
+    A/B flavour of the library only (CELLSEG_LIB_FLAVOUR=ab, `make AB=1`): the production library has no such switch."""
+    if _lib.FLAVOUR != "ab":
+        raise RuntimeError("set_igemm_path: the production library has no A/B switches; run with CELLSEG_LIB_FLAVOUR=ab")
     return _lib.load().cs_set_igemm_path(int(path))
 
 

@@ -24,7 +24,8 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
-        self._plans = {}            # group index -> (key, tensor table, [(t0, n, chunk table, n_chunks)])
+        self._plans = {}            # (group index, tensor addresses, step classes) -> plan; a few entries (alternating parameter sets)
+        self._hsteps = {}           # id(param) -> [address of its `step` tensor, host copy of the value]
 
     def _init_state(self, p):
         st = self.state[p]
@@ -34,32 +35,60 @@ class Adam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
-    def _plan(self, gi, plist):
+    def _host_step(self, p):
+        """Host copy of the parameter's step count: this class is the only writer of `step` (one foreach add per launch), so the
+        tensor is read back only when it was replaced (load_state_dict) or never seen."""
+        st = self.state[p]["step"]
+        h = self._hsteps.get(id(p))
+        if h is None or h[0] != st.data_ptr():
+            h = self._hsteps[id(p)] = [st.data_ptr(), float(st)]
+        return h
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans.clear()
+        self._hsteps.clear()
+
+    _MAX_PLANS = 8
+
+    def _plan(self, gi, plist, classes):
+        """Device tables for one set of parameters.  `classes[i]` numbers the distinct step counts among `plist` in order of first
+        appearance: the bias corrections are per-launch arguments, so parameters at different step counts (the reference's
+        train_alternative, train/train.py:240-268: one optimizer, tile steps and image steps in turn, the encoder ahead of both
+        heads) go to different launches -- one per (step count, <= cs_adam_max_tensors tensors) -- as torch.optim.Adam's
+        per-parameter step allows.  Plans are cached per (parameter set, class pattern), so alternating sets do not re-plan."""
         lib = _lib.load()
-        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel(),
-                     self.state[p]["step"].data_ptr()) for p in plist)
-        cached = self._plans.get(gi)
-        if cached is not None and cached[0] == key:
+        key = (gi, tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in plist),
+               classes)
+        cached = self._plans.get(key)
+        if cached is not None:
             return cached
         dev = plist[0].device
         chunk, cap = lib.cs_adam_chunk_elems(), lib.cs_adam_max_tensors()
-        table = torch.tensor([[k[0], k[1], k[2], k[3]] for k in key], dtype=torch.int64).to(dev)          # CsAdamTensor[] (p, m, v, n)
-        launches = []
-        for t0 in range(0, len(plist), cap):
-            sub = plist[t0:t0 + cap]
-            ch = [(t0 + i, c) for i, p in enumerate(sub) for c in range((p.numel() + chunk - 1) // chunk)]
-            by_step = {float(self.state[p]["step"]) for p in sub}
-            if len(by_step) != 1:
-                raise RuntimeError("cellsegmentation_amd.optim.Adam: parameters of one launch are at different step counts "
-                                   "(a parameter skipped earlier steps); use torch.optim.Adam for such schedules")
-            # [t0, n, chunk table, n_chunks, step count so far (host copy: the per-parameter `step` tensors are advanced with one
-            #  foreach add per step, not read back), the step tensors]
-            launches.append([t0, len(sub), torch.tensor(ch, dtype=torch.int32).to(dev), len(ch), by_step.pop(), [self.state[p]["step"] for p in sub]])
-        self._plans[gi] = (key, table, launches)
-        return self._plans[gi]
+        order = sorted(range(len(plist)), key=lambda i: classes[i])            # stable: members of a class stay in parameter order
+        table = torch.tensor([list(key[1][i]) for i in order], dtype=torch.int64).to(dev)          # CsAdamTensor[] (p, m, v, n)
+        launches, t0 = [], 0
+        while t0 < len(order):
+            t1 = t0
+            while t1 < len(order) and t1 - t0 < cap and classes[order[t1]] == classes[order[t0]]:
+                t1 += 1
+            members = order[t0:t1]
+            ch = [(t0 + j, c) for j, i in enumerate(members) for c in range((plist[i].numel() + chunk - 1) // chunk)]
+            # (first table row, members as indices into plist, chunk table, number of chunks)
+            launches.append((t0, members, torch.tensor(ch, dtype=torch.int32).to(dev), len(ch)))
+            t0 = t1
+        while len(self._plans) >= self._MAX_PLANS:
+            self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = (table, launches)
+        return self._plans[key]
 
     @torch.no_grad()
     def step(self, closure=None):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # the bias corrections are kernel ARGUMENTS computed from a host-side step count: a captured launch would replay the
+            # step number of the capture forever (ADVICE r3)
+            raise RuntimeError("cellsegmentation_amd.optim.Adam.step() cannot be captured into a HIP graph (the step count lives on "
+                               "the host); use torch.optim.Adam(capturable=True) inside graphs")
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -74,16 +103,19 @@ class Adam(torch.optim.Optimizer):
                     raise RuntimeError("cellsegmentation_amd.optim.Adam: contiguous fp32 CUDA parameters with dense fp32 gradients only")
                 self._init_state(p)
             beta1, beta2 = group["betas"]
-            _, table, launches = self._plan(gi, plist)
+            hs = [self._host_step(p) for p in plist]
+            seen = {}
+            classes = tuple(seen.setdefault(h[1], len(seen)) for h in hs)
+            table, launches = self._plan(gi, plist, classes)
             stream = torch.cuda.current_stream(plist[0].device).cuda_stream
-            for ln in launches:
-                t0, n, chunks, n_chunks = ln[0], ln[1], ln[2], ln[3]
-                sub = plist[t0:t0 + n]
-                t = ln[4] + 1.0
-                gts = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in sub]       # (kept alive until the launch is queued)
+            for t0, members, chunks, n_chunks in launches:
+                n = len(members)
+                t = hs[members[0]][1] + 1.0
+                gts = [plist[i].grad if plist[i].grad.is_contiguous() else plist[i].grad.contiguous() for i in members]   # (alive until queued)
                 grads = (ctypes.c_void_p * n)(*[g.data_ptr() for g in gts])
                 _lib.check(lib.cs_adam_step(table.data_ptr(), grads, t0, n, chunks.data_ptr(), n_chunks, float(group["lr"]), float(beta1),
                                             float(beta2), float(group["eps"]), float(group["weight_decay"]), t, stream), "adam_step")
-                ln[4] = t
-                torch._foreach_add_(ln[5], 1.0)
+                for i in members:
+                    hs[i][1] = t
+                torch._foreach_add_([self.state[plist[i]]["step"] for i in members], 1.0)
         return loss

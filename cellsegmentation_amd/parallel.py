@@ -43,9 +43,15 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, force_collectives=False):
+        """`force_collectives`: issue the broadcasts / all-reduces even in a world of ONE rank (a one-rank RCCL communicator is a
+        real communicator: the bucket hand-off, the side-stream ordering and the RCCL launch cost can be exercised and timed on a
+        single GPU -- tests/test_rccl_world1_gpu.py, bench.py --force-reduce).  Requires an initialised process group."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force_collectives and not dist.is_initialized():
+            raise RuntimeError("GradReducer(force_collectives=True) needs torch.distributed to be initialised")
+        self._active = self.world > 1 or bool(force_collectives)       # False: every method is a pass-through
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes = int(bucket_bytes)
         self._stream = None
@@ -55,6 +61,7 @@ class GradReducer:
         self._overlap_ok = True    # this step: gradients may be reduced from inside backward
         self._slot = {}            # id(param) -> (bucket, offset, numel)
         self.launches_in_backward = 0     # buckets sent before reduce() in the last step (diagnostics / tests)
+        self._timed = []
         self._build(list(reversed(self.params)))       # reverse order ~ the order gradients become ready
 
     # ------------------------------------------------------------------ layout
@@ -90,7 +97,7 @@ class GradReducer:
 
     def broadcast_parameters(self, module, src=0):
         """DDP-constructor semantics: rank `src`'s parameters and buffers everywhere."""
-        if self.world == 1:
+        if not self._active:
             return
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src, group=self.group)
@@ -110,7 +117,7 @@ class GradReducer:
     def view_for(self, param):
         """Bucket slice the engine should write this parameter's gradient into (None: not one of ours)."""
         s = self._slot.get(id(param))
-        if s is None or self.world == 1 or param.grad is not None:      # an existing .grad may BE this slice: never write under it
+        if s is None or not self._active or param.grad is not None:      # an existing .grad may BE this slice: never write under it
             return None
         b, o, n = s
         if b.launched:
@@ -120,7 +127,7 @@ class GradReducer:
     def deliver(self, param, grad):
         """The kernels producing `grad` are enqueued on the current stream.  Returns the tensor autograd should see."""
         s = self._slot.get(id(param))
-        if s is None or self.world == 1:
+        if s is None or not self._active:
             return grad
         if id(param) not in self._order_ids:
             self._order_ids.add(id(param))
@@ -154,19 +161,33 @@ class GradReducer:
             for st in b.streams:
                 self._stream.wait_stream(st)
             with torch.cuda.stream(self._stream):
+                if self.time_collectives:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._stream)
                 dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
                 b.flat.mul_(inv)
+                if self.time_collectives:
+                    e1.record(self._stream)
+                    self._timed.append((b.flat.numel() * 4, e0, e1))
         else:
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
             b.flat.mul_(inv)
         b.launched = True
 
     _layout_final = False
+    time_collectives = False          # True: bracket every bucket's all-reduce (+ scale) with events on the side stream
+
+    def collective_times(self):
+        """[(bucket bytes, ms)] of the collectives issued since the last call (synchronises; diagnostics only)."""
+        torch.cuda.synchronize()
+        out = [(n, e0.elapsed_time(e1)) for n, e0, e1 in self._timed]
+        self._timed = []
+        return out
 
     @torch.no_grad()
     def reduce(self):
         """All-reduce(SUM)/world of every .grad, in place (finishes what backward has not already sent)."""
-        if self.world == 1:
+        if not self._active:
             return
         sent_early = sum(1 for b in self.buckets if b.launched)
         for b in self.buckets:

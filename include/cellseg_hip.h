@@ -86,7 +86,13 @@ int cs_bn_apply_stats(const void* z, int dtype, const double* stats, float eps, 
                       float* mean_out, float* rstd_out, long long M, int C, void* stream);
 /* sums fp64 [2][C] (zeroed by caller): sum g, sum g*xhat with xhat=(z-mean)*rstd and g = dy, or for
  * act==CS_ACT_SILU g = dy*silu'(gamma*xhat+beta) (the activation that follows the BN; ReLU gradients are
- * already masked by the consumers, see engine.py). gamma/beta nullable (1/0). */
+ * already masked by the consumers, see engine.py). gamma/beta nullable (1/0).
+ * Two flags may be OR-ed into `act` of cs_bn_bwd_reduce / cs_bn_bwd_apply (the BatchNorm1d layers of the image heads,
+ * resnet.py:132-152, whose backward has no convolution epilogue to do the masking):
+ *   CS_BN_BWD_OWN_RELU  g = dy * [gamma*xhat + beta > 0]: the ReLU that directly follows this normalisation;
+ *   CS_BN_BWD_FROZEN    (apply) the statistics are running statistics (module.eval()): dz = gamma*rstd*g, no batch terms. */
+#define CS_BN_BWD_OWN_RELU 0x100
+#define CS_BN_BWD_FROZEN 0x200
 int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int act, long long M, int C, double* sums, double* workspace, void* stream);
 /* dz = gamma*rstd*( g - sums0/M - xhat*sums1/M ); dgamma=sums1, dbeta=sums0 (fp32, nullable). */
@@ -142,10 +148,13 @@ size_t cs_conv2d_stats_workspace(long long M, int n_out);
 /* Which BM x BN output tile the fwd/dgrad dispatcher uses for M output pixels x n_out channels
  * (returns BM*1000+BN); lets bench.py / profiles name the kernel instantiation that ran. */
 int cs_igemm_tile(long long M, int n_out);
-/* Staging path of the fwd/dgrad kernel: 0 (default) = LDS-DMA (`buffer_load ... lds`) whenever both operands are
- * < 2 GiB; 1 = register-staged everywhere; 3 = LDS-DMA plus the experimental persistent streaming kernel for
- * short-K 1x1 convolutions.  Returns the previous setting. */
+#ifdef CS_AB_SWITCHES
+/* A/B flavour only (`make AB=1` -> libcellseg_hip_ab.so; not part of the production ABI).  Staging path of the fwd/dgrad
+ * kernel: 0 (default) = LDS-DMA (`buffer_load ... lds`) whenever both operands are < 2 GiB; 1 = register-staged everywhere
+ * (the production rule for operands >= 2 GiB, forced here so that small test shapes reach it); 3 = LDS-DMA plus the
+ * experimental persistent streaming kernel for short-K 1x1 convolutions.  Returns the previous setting. */
 int cs_set_igemm_path(int path);
+#endif
 /* data gradient: dx = ( conv_transpose(dy, w) + add ) * [mask > 0]; add/mask nullable, both shaped like x.
  *   `mask` is the conv's own input activation when that input came out of a ReLU (the ReLU backward of
  *   resnet.py:41/76 fused here). colsum (nullable fp32 [C]) accumulates per-channel sums of the stored dx. */

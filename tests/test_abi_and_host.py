@@ -18,13 +18,32 @@ GOLD = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"), a
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "cellseg_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", header)))
+    # entry points of the A/B flavour (`make AB=1`) sit in #ifdef CS_AB_SWITCHES blocks: not part of the production ABI
+    ab_blocks = re.findall(r"#ifdef CS_AB_SWITCHES(.*?)#endif", header, flags=re.S)
+    ab_only = sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", "".join(ab_blocks))))
+    production = re.sub(r"#ifdef CS_AB_SWITCHES.*?#endif", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", production)))
     assert len(declared) >= 30
+    assert _lib.FLAVOUR == "", "the CPU suite checks the production library"
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/cellseg_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == declared, "ctypes signature table out of sync with the header"
+    assert sorted(_lib._AB_SIGNATURES) == ab_only
+    for name in ab_only:
+        assert not hasattr(lib, name), f"{name} is an A/B switch: it must not be exported by the production library"
     assert lib.cs_abi_version() >= 3
+
+
+def test_production_library_reads_no_environment():
+    """the CELLSEG_* launch-rule knobs exist in the A/B flavour only -- the production library does not even
+    import getenv."""
+    import subprocess
+    r = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    undefined = {line.split()[-1].split("@")[0] for line in r.stdout.splitlines() if line.strip()}
+    assert "hipLaunchKernel" in undefined or any(s.startswith("hip") for s in undefined)
+    assert "getenv" not in undefined and "secure_getenv" not in undefined
 
 
 def test_argument_checks_without_gpu():

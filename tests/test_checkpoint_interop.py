@@ -1,6 +1,7 @@
 """CPU: checkpoint files of the three stages -- structure, per-stage parameter filters, hand-off and
 resume paths; and, where the reference checkout is present, a round trip through the reference's own model class."""
 import os
+import sys
 
 import pytest
 import torch
@@ -9,6 +10,7 @@ from cellsegmentation_amd import checkpoint as C
 from cellsegmentation_amd.model import resnet as R
 
 REF = "/root/reference"
+sys.dont_write_bytecode = True      # the reference tree is read-only: no __pycache__ beside its sources
 
 
 def _tiny_opt(m):

@@ -13,6 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
+sys.dont_write_bytecode = True      # the reference tree is read-only: no __pycache__ beside its sources
 DRIVERS = ["train_image.py", "train_tile.py", "train_seg.py", "test_count.py", "test_tile.py", "test_seg.py", "train_ensemble.py"]
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")

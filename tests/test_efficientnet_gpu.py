@@ -110,7 +110,8 @@ def _pair(arch, dev, dtype=torch.float32, sd_prob=0.0):
     return m.to(dev).set_compute_dtype(dtype), osd
 
 
-@pytest.mark.parametrize("arch,size,n", [("efficientnet_b0", 64, 4), ("efficientnet_b3", 96, 2)])
+# B0 and B2 are the reference's two factories (model/efficientnet.py:417-440); B3 is the same rule at w = 1.2, d = 1.4 (BASELINE config 4)
+@pytest.mark.parametrize("arch,size,n", [("efficientnet_b0", 64, 4), ("efficientnet_b2", 64, 2), ("efficientnet_b3", 96, 2)])
 def test_efficientnet_tile_and_image_vs_oracle(arch, size, n, dev):
     x = synth.normalise(synth.ihc_tiles(n, size, 51))
     labels = torch.tensor([i % 2 for i in range(n)])
@@ -223,7 +224,7 @@ def test_depthwise_tiled_kernels_everywhere_the_geometry_allows(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("2", "1", "0"):
-        env = dict(os.environ, CELLSEG_DW_UNTILED=mode, CELLSEG_DW_NOSTRIP="1")
+        env = dict(os.environ, CELLSEG_DW_UNTILED=mode, CELLSEG_DW_NOSTRIP="1", CELLSEG_LIB_FLAVOUR="ab")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_efficientnet_gpu.py"), "-m", "gpu", "-x", "-q",
                             "-k", "test_depthwise_conv"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])

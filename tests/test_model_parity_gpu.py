@@ -15,8 +15,24 @@ from cellsegmentation_amd import synth  # noqa: E402
 from cellsegmentation_amd import functional as HF  # noqa: E402
 from cellsegmentation_amd.model import resnet as R  # noqa: E402
 
-GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"), allow_pickle=False)
-FACT = {"resnet18": R.MILresnet18, "resnet34": R.MILresnet34, "resnet50": R.MILresnet50, "resnext50_32x4d": R.MILresnext50_32x4d}
+class _Vectors:
+    """reference_vectors.npz (tests/golden/make_golden.py) plus reference_vectors_x101.npz (make_golden_x101.py: ResNeXt-101 32x8d,
+    model/resnext.py:431-442), read as one mapping."""
+
+    def __init__(self, *names):
+        self._files = [np.load(os.path.join(os.path.dirname(__file__), "golden", n), allow_pickle=False) for n in names]
+        self.files = [k for f in self._files for k in f.files]
+
+    def __getitem__(self, key):
+        for f in self._files:
+            if key in f.files:
+                return f[key]
+        raise KeyError(key)
+
+
+GOLD = _Vectors("reference_vectors.npz", "reference_vectors_x101.npz")
+FACT = {"resnet18": R.MILresnet18, "resnet34": R.MILresnet34, "resnet50": R.MILresnet50, "resnext50_32x4d": R.MILresnext50_32x4d,
+        "resnext101_32x8d": R.MILresnext101_32x8d}
 RTOL = 1e-4          # logits / loss / probabilities (north_star tolerance)
 GTOL = 5e-3          # gradients: ~3x the reference's own fp32-vs-fp64 noise (1.5e-3, tests/golden/measure_fp32_noise.py)
 # train-mode BN makes gradients far worse conditioned (36 samples/channel in layer4 at 96x96): measured noise of the
@@ -74,7 +90,7 @@ def check_grads(tag, params, errs, rtol, keys=None):
 
 
 @pytest.mark.parametrize("arch,size", [("resnet18", 32), ("resnet18", 299), ("resnet34", 64), ("resnet50", 32), ("resnet50", 299),
-                                       ("resnext50_32x4d", 64)])
+                                       ("resnext50_32x4d", 64), ("resnext101_32x8d", 64)])
 def test_tile_mode_matches_reference_fp32(arch, size, dev):
     tag = f"{arch}/tile{size}"
     n, seed = int(GOLD[f"{tag}/n"]), int(GOLD[f"{tag}/seed"])

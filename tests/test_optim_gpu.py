@@ -70,3 +70,53 @@ def test_adam_skips_parameters_without_gradients_and_unaligned_views(dev):
     assert len(a.state[p3]) == 0
     with pytest.raises(ValueError):
         O.Adam([p1], amsgrad=True)
+
+
+def test_adam_alternating_parameter_sets_at_different_step_counts(dev):
+    """The reference's train_alternative (train/train.py:240-268): ONE optimizer, tile steps (encoder + tile head have gradients)
+    and image steps (encoder + image heads) in turn, zero_grad(set_to_none=True) in between -- after the first tile step the encoder
+    is one step ahead of the image heads, then two, ...  torch.optim.Adam keeps a step count per parameter; so does this class:
+    one launch per distinct step count, plans cached per parameter set."""
+    shapes = {"enc": [(64, 3, 7, 7), (64,), (128, 64, 3, 3)], "tile": [(2, 128), (2,)], "img": [(7, 128), (7,), (1, 128)]}
+    g = torch.Generator().manual_seed(3)
+    mk = lambda: {k: [torch.randn(s, generator=torch.Generator().manual_seed(11 + i)).to(dev).requires_grad_() for i, s in enumerate(v)]
+                  for k, v in shapes.items()}
+    ours, ref = mk(), mk()
+    flat = lambda d: d["enc"] + d["tile"] + d["img"]
+    a = O.Adam(flat(ours), lr=5e-4, weight_decay=1e-4)
+    b = torch.optim.Adam(flat(ref), lr=5e-4, weight_decay=1e-4)
+    plans = []
+    for step in range(7):
+        active = ("enc", "tile") if step % 2 == 0 else ("enc", "img")
+        for grp in shapes:
+            for p, q in zip(ours[grp], ref[grp]):
+                if grp in active:
+                    gr = torch.randn(p.shape, generator=g).to(dev)
+                    p.grad, q.grad = gr, gr.clone()
+                else:
+                    p.grad = q.grad = None
+        a.step()
+        b.step()
+        plans.append(len(a._plans))
+    torch.cuda.synchronize()
+    for p, q in zip(flat(ours), flat(ref)):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
+        assert float(a.state[p]["step"]) == float(b.state[q]["step"])
+    assert float(a.state[ours["enc"][0]]["step"]) == 7.0 and float(a.state[ours["tile"][0]]["step"]) == 4.0 and float(a.state[ours["img"][0]]["step"]) == 3.0
+    assert plans[-1] == plans[3] <= 3, plans          # steady state: no new plan per step (all-equal tile set, tile set one behind, image set)
+
+
+def test_adam_step_refuses_stream_capture(dev):
+    p = torch.randn(1000, device=dev, requires_grad=True)
+    a = O.Adam([p], lr=1e-3)
+    p.grad = torch.ones_like(p)
+    a.step()                                  # warm: the plan exists
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(graph, stream=s):
+                a.step()
+    torch.cuda.synchronize()

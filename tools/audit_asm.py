@@ -107,9 +107,11 @@ def audit_build(verbose=False):
         if not os.path.exists(path):
             out.append(f"{path}: missing (run `make -C cellsegmentation_amd/csrc`)")
             continue
-        src = os.path.join(ROOT, "cellsegmentation_amd", "csrc", stem + ".hip")
-        if os.path.getmtime(path) < os.path.getmtime(src):
-            out.append(f"{path}: older than {stem}.hip (stale assembly)")
+        deps = [os.path.join(ROOT, "cellsegmentation_amd", "csrc", stem + ".hip"), os.path.join(ROOT, "cellsegmentation_amd", "csrc", "cs_common.h"),
+                os.path.join(ROOT, "include", "cellseg_hip.h")]
+        stale = [os.path.basename(d) for d in deps if os.path.getmtime(path) < os.path.getmtime(d)]
+        if stale:
+            out.append(f"{path}: older than {', '.join(stale)} (stale assembly; the Makefile regenerates every owned-register stem together)")
             continue
         stats = audit_text(open(path).read(), rules)
         for pat, _ in rules:

@@ -48,7 +48,8 @@ def main():
     iters = int(os.environ.get("ITERS", "20"))
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if os.environ.get("DTYPE", "bf16") == "bf16" else torch.float32
-    K.set_igemm_path(int(os.environ.get("IGEMM_PATH", "0")))
+    if os.environ.get("IGEMM_PATH", "0") != "0":       # A/B flavour only (CELLSEG_LIB_FLAVOUR=ab)
+        K.set_igemm_path(int(os.environ["IGEMM_PATH"]))
     for name in names:
         N, H, W, C, Kc, R, s, p = SHAPES[name]
         g = K.make_geom(N, H, W, C, Kc, R, R, s, p)
