@@ -391,9 +391,11 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        t_host = (time.perf_counter() - t0) / steps          # host time to ENQUEUE a step (the GPU may still be running)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         early = red.launches_in_backward
+        aliased = sum(1 for p in params if p.grad is not None and red._slot[id(p)][2] == p.grad.data_ptr())
         red.time_collectives = True
         step()
         times = red.collective_times()
@@ -402,6 +404,7 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
         if own_pg:
             dist.destroy_process_group()
     return {"ms_per_step_with_collectives": round(dt * 1e3, 3), "tiles_per_s": round(BAG / dt, 1), "steps": steps,
+            "host_enqueue_ms_per_step": round(t_host * 1e3, 3), "gradients_aliasing_their_bucket": f"{aliased}/{len(params)}",
             "buckets": len(red.buckets), "buckets_sent_inside_backward": early,
             "allreduce_ms_per_step": round(sum(t for _, t in times), 4),
             "per_bucket": [{"mbytes": round(n / 1e6, 2), "ms": round(t, 4)} for n, t in times],
@@ -497,6 +500,7 @@ def main():
     else:
         for _ in range(args.steps):
             step()
+    host_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic: host- or GPU-bound)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -533,6 +537,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -710,6 +710,212 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
 
 
 // =================================================================================================
+// Wide kernel (round 4): the halo structure at ONE wave per SIMD with all 512 registers of a lane.
+//   * workgroup tile = (32 * TM) pixels x 128 channels, TM = 4 / 6 / 8; the four waves still split the channels (1 x 4) and stream
+//     the packed weights of their own 32 channels from L2, so a wave multiplies 32 * TM pixels per 1 KiB weight fragment instead
+//     of 96-128: per 16-deep step TM MFMA are fed by TM ds_read_b128 + ONE buffer_load_dwordx4.
+//   * accumulators live in AGPRs a[128 : 128 + 16 * TM): 128 registers at TM = 8, which no 256-register wave can hold beside its
+//     operands.  (hipcc uses LOW AGPRs as spill space for its own VGPRs when it runs short; the audit checks that it never names
+//     a[128] or above.)
+//   * the weight stream is a ring of 18 fragment slots at 16-deep granularity (72 VGPRs): a slot is refilled the moment its MFMAs
+//     are issued, so 17 steps (4.25 taps; the halo kernel: 2 taps) of weights are in flight -- at one wave per SIMD nobody else
+//     covers an L2 round trip.  36 steps per chunk = 2 x 18: slot numbers are compile-time constants in every chunk.
+//   * ONE chunk body (9 taps, 36 steps) looped at run time: the LDS stage of a chunk is part of the operand-row addresses, loads
+//     past the end are issued out of range (they count in vmcnt, move nothing), so every s_waitcnt immediate is the same in
+//     every chunk -- a quarter of the halo kernel's code per pixel tile.
+// Register map: v[100:103] temporaries, v[104:119] operand-row addresses (two sets of 8), v[120:183] pixel fragments (two sets
+// of 8 x b128), v[184:255] weight ring; the compiler is capped at v0..v99 as in the other kernels of this file.
+// =================================================================================================
+constexpr int W_TMP = 100, W_AD = 104, W_AF = 120, W_B = 184, W_ACC = 128, W_NSLOT = 18;
+
+template <int N, typename F> __device__ __forceinline__ void for_n(F&& f) {
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (f.template operator()<Is>(), ...); }(std::make_integer_sequence<int, N>{});
+}
+template <int REG> __device__ __forceinline__ void azero() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(REG)); }
+template <int REG> __device__ __forceinline__ float aget() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(REG));
+    return x;
+}
+template <int I> __device__ __forceinline__ f32x16 acc_read_w() {
+    f32x16 d;
+    [&]<int... Rs>(std::integer_sequence<int, Rs...>) { ((d[Rs] = aget<W_ACC + 16 * I + Rs>()), ...); }(std::make_integer_sequence<int, 16>{});
+    return d;
+}
+template <int ACC, int B, int A> __device__ __forceinline__ void mfma_w() {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"i"(ACC), "i"(ACC + 15), "i"(B), "i"(B + 3), "i"(A),
+                 "i"(A + 3));
+}
+// the 1 KiB weight fragment of one 16-deep step of this wave's 32 output channels -> ring slot SLOT
+template <int SLOT> __device__ __forceinline__ void bload1(const i32x4& rsrc, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 v[%c3:%c4], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff), "i"(W_B + 4 * SLOT), "i"(W_B + 4 * SLOT + 3));
+}
+// operand-row address of pixel-tile register q shifted by `sh` rows -> v[A]; hhs = chunk-column bit of the lane half + LDS stage base
+template <int A> __device__ __forceinline__ void addr1_w(unsigned q, unsigned sh, unsigned hhs, unsigned cf0) {
+    asm volatile("v_add_lshl_u32 v[%c[a]], %[q], %[sh], 4\n\t"
+                 "v_and_b32 v[%c[t]], 0xffffff00, v[%c[a]]\n\t"
+                 "v_and_or_b32 v[%c[a]], v[%c[a]], %[cf0], %[hhs]\n\t"
+                 "v_lshl_add_u32 v[%c[a]], v[%c[t]], 3, v[%c[a]]"
+                 ::[q] "v"(q), [sh] "s"(sh), [hhs] "v"(hhs), [cf0] "s"(cf0), [a] "i"(A), [t] "i"(W_TMP));
+}
+
+// One tap (four 16-deep steps) of a TM x (32 px x 32 ch) wave tile.  T = tap of the chunk; step n = 4 * T + s uses weight slot n % 18
+// and fragment set s & 1; every MFMA is followed by the read that refills its fragment registers for step s + 2 (same tap) or for
+// steps 0 / 1 of the next tap (address set 1 - S).  The last tap of a chunk reads nothing ahead (the next stage is only visible
+// behind the barrier), the first starts cold.  NBW: 16-row LDS blocks this wave fetches per chunk, block j at step 2 * j.
+template <int TM, int NBW, int T, int NTAP, typename Pre>
+__device__ __forceinline__ void tap_wide(const unsigned (&qb)[TM], unsigned sh_cur, unsigned sh_next, unsigned hhs, unsigned cf0, Pre&& pre_step) {
+    constexpr int S = T & 1;
+    constexpr int A = W_AD + 8 * S, NA = W_AD + 8 * (1 - S);
+    constexpr int F0 = W_AF, F1 = W_AF + 32;
+    constexpr int W = 2 * TM - 1 < 15 ? 2 * TM - 1 : 15;
+    constexpr bool COLD = T == 0, AHEAD = T != NTAP - 1;
+    pre_step.template operator()<4 * T + 0>();
+    if constexpr (COLD) {
+        for_n<TM>([&]<int i>() { addr1_w<A + i>(qb[i], sh_cur, hhs, cf0); });
+        for_n<TM>([&]<int i>() { lds_rd<F0 + 4 * i, A + i, 0u>(); });
+        for_n<TM>([&]<int i>() { lds_rd<F1 + 4 * i, A + i, 512u>(); });
+    }
+    constexpr int B0 = W_B + 4 * ((4 * T + 0) % W_NSLOT), B1 = W_B + 4 * ((4 * T + 1) % W_NSLOT), B2 = W_B + 4 * ((4 * T + 2) % W_NSLOT),
+                  B3 = W_B + 4 * ((4 * T + 3) % W_NSLOT);
+    // (the next tap's addresses -- 4 VALU per pixel tile -- ride in every other MFMA gap of steps 0 and 1: as one block in front of
+    // the tap they would leave the matrix pipe idle for ~130 cycles)
+    static_assert(TM % 2 == 0, "address interleave");
+    for_n<TM>([&]<int i>() {
+        wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B0, F0 + 4 * i>(); lds_rd<F0 + 4 * i, A + i, 1024u>();
+        if constexpr (AHEAD && i % 2 == 0) addr1_w<NA + i / 2>(qb[i / 2], sh_next, hhs, cf0);
+    });
+    pre_step.template operator()<4 * T + 1>();
+    for_n<TM>([&]<int i>() {
+        wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B1, F1 + 4 * i>(); lds_rd<F1 + 4 * i, A + i, 1536u>();
+        if constexpr (AHEAD && i % 2 == 0) addr1_w<NA + TM / 2 + i / 2>(qb[TM / 2 + i / 2], sh_next, hhs, cf0);
+    });
+    pre_step.template operator()<4 * T + 2>();
+    if constexpr (AHEAD) {
+        for_n<TM>([&]<int i>() { wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B2, F0 + 4 * i>(); lds_rd<F0 + 4 * i, NA + i, 0u>(); });
+        pre_step.template operator()<4 * T + 3>();
+        for_n<TM>([&]<int i>() { wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B3, F1 + 4 * i>(); lds_rd<F1 + 4 * i, NA + i, 512u>(); });
+    } else {
+        for_n<TM>([&]<int i>() { wait_lgkm<(2 * TM - 1 - i < 15 ? 2 * TM - 1 - i : 15)>(); mfma_w<W_ACC + 16 * i, B2, F0 + 4 * i>(); });
+        pre_step.template operator()<4 * T + 3>();
+        for_n<TM>([&]<int i>() { wait_lgkm<TM - 1 - i>(); mfma_w<W_ACC + 16 * i, B3, F1 + 4 * i>(); });
+    }
+}
+
+template <int TM, int NBW, bool DG>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(50))) void conv2_wide_kernel(C2Params p) {
+    static_assert(TM >= 2 && TM <= 8 && NBW >= 1 && NBW <= 9, "register map / DMA schedule");
+    constexpr int NTAP = 9, SK = 3, NSTEP = 4 * NTAP;
+    static_assert(NSTEP % W_NSLOT == 0, "slot numbers must repeat from chunk to chunk");
+    static_assert(2 * (NBW - 1) < NSTEP - (W_NSLOT - 1), "every DMA piece of a chunk must be older than the weights of its last step");
+    constexpr int BM = TM * 32, BN = 128;
+    constexpr unsigned STAGE = NBW * 4 * 2048;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    // XCD-aware tile order: id = 8*slot + xcd, all channel tiles of one pixel tile back to back on one XCD
+    const unsigned bid = blockIdx.x;
+    const unsigned slot = bid >> 3;
+    const unsigned mtile = (slot / (unsigned)p.n_ntiles) * 8u + (bid & 7u);
+    const unsigned m0 = mtile * BM;
+    if (m0 >= p.M) return;
+    const int n0 = (int)(slot % (unsigned)p.n_ntiles) * BN;
+    const int n_w = n0 + wave * 32;
+    const bool alive = n_w < p.NOUT;
+
+    Epilogue<TM, false, DG, TileOffs> epi(p, m0, n_w, mtile, alive, 0u);
+    unsigned qb[TM];
+    unsigned voff[NBW];
+    {
+        auto pos0 = [&](unsigned m) -> unsigned {      // padded-linear position of tap offset (0,0) of destination pixel m
+            const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+            const unsigned x = m - yall * (unsigned)p.DW;
+            const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+            const unsigned y = yall - n * (unsigned)p.DH;
+            return (n * (unsigned)p.Hp + y) * (unsigned)p.Wp + x;
+        };
+        const unsigned Lmin = pos0(m0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            unsigned m = m0 + 32u * i + (unsigned)l31;
+            if (m > p.M - 1) m = p.M - 1;
+            qb[i] = pos0(m) - Lmin;
+        }
+        // this wave's LDS blocks: b = wave + 4j; lane -> (row 16b + (lane & 15), chunk column lane >> 4 (+4 for the second piece))
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const unsigned L = Lmin + 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+            const unsigned row = udivm(L, p.mg_wp, p.sh_wp);
+            const unsigned col = L - row * (unsigned)p.Wp;
+            const unsigned n = udivm(row, p.mg_hp, p.sh_hp);
+            const unsigned ry = row - n * (unsigned)p.Hp;
+            const bool real = col >= (unsigned)p.PW && ry >= (unsigned)p.PH && n < (unsigned)p.NS;
+            const unsigned pix = (n * (unsigned)p.SH + (ry - (unsigned)p.PH)) * (unsigned)p.SW + (col - (unsigned)p.PW);
+            voff[j] = real ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
+        }
+    }
+    const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
+    const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
+    const unsigned bvoff = alive ? (unsigned)lane * 16u : OOB;
+    unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)p.NCC * (unsigned)(NTAP * 4096);
+    const unsigned smem_base = lds_off(smem);
+
+    epi.prefetch();
+    asm volatile("; v[100:255] and a[128:255] are owned by the main loop" ::: "v100", "v255", "a128", "a255");
+    for_n<16 * TM>([&]<int r>() { azero<W_ACC + r>(); });
+    const unsigned cf0 = 0xf0u;
+
+    // ---- prologue: chunk 0 of the operand rows, weights of steps 0 .. 16
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) dma_block(rsrc_a, smem_base + (unsigned)(wave + 4 * j) * 2048u, voff[j], 0u);
+    for_n<W_NSLOT - 1>([&]<int k>() { bload1<k>(rsrc_b, bvoff, wsoff); wsoff += 1024u; });
+    wait_vm<W_NSLOT - 1>();
+    raw_barrier();
+
+    const int NCC = p.NCC;
+    for (int cc = 0; cc < NCC; ++cc) {
+        const unsigned cur = (cc & 1) ? STAGE : 0u, nxt = STAGE - cur;
+        const unsigned hhs = (unsigned)hh * 256u + cur;
+        const bool more = cc + 1 < NCC;
+        const unsigned nxt_soff = (unsigned)(cc + 1) * 128u;
+        // in front of the MFMAs of step n: refill the slot step n - 1 has just released with the weights of step n + 17, send this
+        // step's share of the next chunk's rows, then wait until the weights of step n have landed (17 younger loads + the DMA
+        // pieces issued since then stay in flight)
+        auto pre_step = [&]<int n>() {
+            bload1<(n + W_NSLOT - 1) % W_NSLOT>(rsrc_b, bvoff, wsoff);
+            wsoff += 1024u;
+            if constexpr (n % 2 == 0 && n / 2 < NBW) {
+                constexpr int j = n / 2;
+                dma_block(rsrc_a, smem_base + nxt + (unsigned)(wave + 4 * j) * 2048u, more ? voff[j] : OOB, nxt_soff);
+            }
+            constexpr int lo = n - (W_NSLOT - 1) > 0 ? n - (W_NSLOT - 1) : 0;
+            constexpr int first = (lo + 1) / 2, last = n / 2 < NBW - 1 ? n / 2 : NBW - 1;       // blocks j with lo <= 2j <= n
+            constexpr int pieces = last >= first ? 2 * (last - first + 1) : 0;
+            wait_vm<W_NSLOT - 1 + pieces>();
+        };
+        for_n<NTAP>([&]<int T>() {
+            const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.LW + (unsigned)(T % SK);
+            const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.LW + (unsigned)((T + 1) % SK);
+            tap_wide<TM, NBW, T, NTAP>(qb, sh_cur, sh_next, hhs, cf0, pre_step);
+        });
+        // every wave's pieces of the next chunk have landed (the wait of step 35 is younger than all of them) and this stage is read out
+        raw_barrier();
+        if (!more) epi.scr = smem_base + nxt + (unsigned)wave * EPI_WAVE;
+    }
+    // MFMA results -> VALU reads: the last MFMA needs its 16 passes (no hardware interlock on this path)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7");
+    for_n<TM>([&]<int i>() {
+        const f32x16 d = acc_read_w<i>();
+        epi.template operator()<i>(d);
+    });
+    epi.finish();
+    wait_vm<0>();                     // the out-of-range tail loads are gone before the registers / LDS are released
+}
+
+// =================================================================================================
 // Ring kernel: 1x1 convolutions of ANY contraction depth as a persistent, software-pipelined stream.  Stamped, a one-shot
 // workgroup (load the whole pixel tile, one barrier, multiply, epilogue -- round 2's first 1x1 kernel) spends most of its life with nothing in flight (first-load latency, then an epilogue behind
 // which no load is queued); two such workgroups per compute unit reach 3.4-4.3 TB/s on the layers that are HBM-bound, and the
@@ -1160,13 +1366,36 @@ void magic(unsigned d, unsigned& mg, unsigned& sh) {
     sh = (unsigned)(l - 1);
 }
 
-// geometry of the packed-operand launch; cfg: 0 = not served, 1 = 128 px x 128 ch (1x4 waves), 2 = 256 px x 64 ch (2x2 waves)
+// geometry of the packed-operand launch; cfg: 0 = not served, 1 = 128 px x 128 ch (1x4 waves), 2 = 256 px x 64 ch (2x2 waves),
+// 3 = wide kernel (one wave per SIMD), (32 * tm) px x 128 ch
 struct C2Plan {
     int cfg, nbw, ncc, rows;       // rows = partial column-sum rows
-    int tm;                        // pixel tiles (32 px) per wave: 1 x 4 configuration only
+    int tm;                        // pixel tiles (32 px) per wave: 1 x 4 configurations only
     int t2d;                       // halo kernel on 8 x 16-pixel tiles (wide images)
     C2Params p;
 };
+
+// Pixel-tile height of the wide kernel (one workgroup per compute unit: 256 run at once).  The busiest compute unit sets the time:
+// rounds-of-residency x tile height, the taller tile on ties (fewer weight passes).  0 = do not use the wide kernel.
+// CELLSEG_WIDE (A/B flavour): 1 = never, 4 / 6 / 8 = force that height wherever the window fits.
+int pick_wide_tm(long long M, int n_ntiles, int ncc) {
+    static const int knob = cs_env_int_("CELLSEG_WIDE", 0);
+    if (knob == 1) return 0;
+    if (knob == 4 || knob == 6 || knob == 8) return knob;
+    if (ncc < 2) return 0;
+    int best = 0;
+    long long best_cost = 1ll << 60, best_tiles = 0;
+    for (int tm = 8; tm >= 4; tm -= 2) {
+        const long long tiles = ((M + 32 * tm - 1) / (32 * tm)) * n_ntiles;
+        const long long cost = ((tiles + 255) / 256) * tm;
+        if (cost < best_cost) { best_cost = cost; best = tm; best_tiles = tiles; }
+    }
+    // Measured (tools/wide_ab.sh, profiles/round4_notes.md): with every tile resident at once -- one round -- the wide kernel is ahead
+    // of two 4-wave halo workgroups per compute unit (ResNet-50 layer3 34.2 -> 31.0 us, layer4 41.8 -> 33.9 us, decoder 1024 -> 512
+    // 106 -> 96 us); with a second round its serial prologue and epilogue are paid twice with nothing to hide them behind
+    // (layer2: 32.7 -> 40.2 us), and the halo kernel stays.
+    return best_tiles <= 256 ? best : 0;
+}
 
 // Pixel-tile height of the 1 x 4 halo configuration.  Workgroups do not run in lock-step rounds, so a shorter tile only pays
 // where the whole grid is resident at once (<= 512 workgroups on 256 compute units, two each) and the busiest compute unit's
@@ -1207,6 +1436,15 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     };
     int cfg = 0, nbw = 0, tm = 4;
     if (NOUT % 128 == 0) {
+        // wide kernel first: window blocks per wave rounded up to an instantiated count (TM 4: 3 / 5, TM 6: 5 / 7, TM 8: 7 / 9)
+        const int wtm = pick_wide_tm(M, NOUT / 128, ncc);
+        if (wtm) {
+            const int nb = (window_blocks(32 * wtm) + 3) / 4;
+            const int lo = wtm == 4 ? 3 : wtm == 6 ? 5 : 7;
+            if (nb <= lo + 2) { cfg = 3; tm = wtm; nbw = nb <= lo ? lo : lo + 2; }
+        }
+    }
+    if (!cfg && NOUT % 128 == 0) {
         tm = pick_tm(M, NOUT / 128);
         for (; tm <= 4; ++tm) {              // a shorter tile has a smaller window; fall back to taller ones only if it somehow does not fit
             const int nb = (window_blocks(32 * tm) + 3) / 4;
@@ -1246,11 +1484,11 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     const unsigned long long wbytes = (unsigned long long)cs_ceil_div(NOUT, 32) * 32 * g->R * g->S * (unsigned long long)SC * 2ull;
     if (wbytes >= 0x80000000ull) return false;
     p.wpk_bytes = (unsigned)wbytes;
-    const int BM = cfg == 1 ? 32 * tm : 256, BN = cfg == 1 ? 128 : 64;
+    const int BM = cfg != 2 ? 32 * tm : 256, BN = cfg != 2 ? 128 : 64;
     p.n_ntiles = cs_ceil_div(NOUT, BN);
-    pl.cfg = cfg; pl.nbw = nbw; pl.ncc = ncc; pl.tm = cfg == 1 ? tm : 4;
+    pl.cfg = cfg; pl.nbw = nbw; pl.ncc = ncc; pl.tm = cfg != 2 ? tm : 4;
     pl.t2d = t2d;
-    pl.rows = t2d ? (int)p.n_tiles : cs_ceil_div(M, BM) * (cfg == 1 ? 1 : 2);
+    pl.rows = t2d ? (int)p.n_tiles : cs_ceil_div(M, BM) * (cfg != 2 ? 1 : 2);
     return true;
 }
 // group count of a ring launch (a multiple of 8: one group per XCD slot): minimises rounds-of-residency x pixel tiles per workgroup;
@@ -1394,9 +1632,36 @@ int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
     return CS_OK;
 }
 
+template <int TM, int NBW, bool DG>
+int launch_wide(const C2Params& p, hipStream_t st) {
+    const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 32 * TM);
+    dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
+    const size_t lds = (size_t)NBW * 8192 * 2;           // two stages; the epilogue's exchange scratch borrows the idle one
+    auto fn = conv2_wide_kernel<TM, NBW, DG>;
+    if (!allow_lds(fn, lds)) return CS_ERR_LAUNCH;
+    char name[64];
+    snprintf(name, sizeof(name), "conv2_wide_kernel<%d,%d,%s>", TM, NBW, DG ? "true" : "false");
+    cs_set_variant_(name);
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
 template <bool DG>
 int launch_halo(const C2Plan& pl, hipStream_t st) {
     const C2Params& p = pl.p;
+    if (pl.cfg == 3) {
+        switch (pl.tm * 16 + pl.nbw) {
+            case 4 * 16 + 3: return launch_wide<4, 3, DG>(p, st);
+            case 4 * 16 + 5: return launch_wide<4, 5, DG>(p, st);
+            case 6 * 16 + 5: return launch_wide<6, 5, DG>(p, st);
+            case 6 * 16 + 7: return launch_wide<6, 7, DG>(p, st);
+            case 8 * 16 + 7: return launch_wide<8, 7, DG>(p, st);
+            case 8 * 16 + 9: return launch_wide<8, 9, DG>(p, st);
+        }
+        cs_set_error_("conv2: no wide-kernel instantiation for this plan");
+        return CS_ERR_UNSUPPORTED;
+    }
     if (pl.cfg == 2) {
         const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 256);
         dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
@@ -1434,8 +1699,8 @@ extern "C" int cs_debug_set_stamp_buffer(void* p) { g_dbg_buf = reinterpret_cast
 // ---------------------------------------------------------------------------------------------------------------------
 static bool plan_any(const CsConvGeom* g, int dgrad, C2Plan& pl) { return plan_halo(g, dgrad, pl) || plan_gemm(g, dgrad, pl); }
 static int launch_any(const C2Plan& pl, hipStream_t st, bool dg) {
-    if (dg) return pl.cfg <= 2 ? launch_halo<true>(pl, st) : launch_gemm<true>(pl, st);
-    return pl.cfg <= 2 ? launch_halo<false>(pl, st) : launch_gemm<false>(pl, st);
+    if (dg) return pl.cfg <= 3 ? launch_halo<true>(pl, st) : launch_gemm<true>(pl, st);
+    return pl.cfg <= 3 ? launch_halo<false>(pl, st) : launch_gemm<false>(pl, st);
 }
 
 extern "C" int cs_conv2d_packed_supported(const CsConvGeom* g, int dgrad) {

@@ -32,11 +32,12 @@ _ALIGN = 64      # floats: every bucket slice starts on a 256-byte boundary
 
 
 class _Bucket:
-    __slots__ = ("flat", "items", "pending", "launched", "streams")
+    __slots__ = ("flat", "items", "views", "pending", "launched", "streams")
 
     def __init__(self, n, device):
         self.flat = torch.zeros((n,), dtype=torch.float32, device=device)
         self.items = []          # (param, offset, numel)
+        self.views = []          # the slice of `flat` shaped like each parameter (made once: slicing costs microseconds per call)
         self.pending = 0
         self.launched = False
         self.streams = set()     # streams whose kernels wrote gradients into this bucket since the last reduce()
@@ -73,7 +74,9 @@ class GradReducer:
             b = _Bucket(cur_n, cur[0][0].device)
             for p, o, n in cur:
                 b.items.append((p, o, n))
-                self._slot[id(p)] = (b, o, n)
+                view = b.flat[o:o + n].view_as(p)
+                b.views.append(view)
+                self._slot[id(p)] = (b, view, view.data_ptr())
             self.buckets.append(b)
 
         for p in ordered:
@@ -119,10 +122,10 @@ class GradReducer:
         s = self._slot.get(id(param))
         if s is None or not self._active or param.grad is not None:      # an existing .grad may BE this slice: never write under it
             return None
-        b, o, n = s
+        b, view, _ = s
         if b.launched:
             raise RuntimeError("GradReducer: a second backward() before reduce(); call reduce() once per backward")
-        return b.flat[o:o + n].view_as(param)
+        return view
 
     def deliver(self, param, grad):
         """The kernels producing `grad` are enqueued on the current stream.  Returns the tensor autograd should see."""
@@ -132,7 +135,7 @@ class GradReducer:
         if id(param) not in self._order_ids:
             self._order_ids.add(id(param))
             self._order.append(param)
-        b, o, n = s
+        b, view, vptr = s
         if b.launched:
             raise RuntimeError("GradReducer: a second backward() before reduce(); call reduce() once per backward")
         if param.grad is not None:
@@ -140,8 +143,7 @@ class GradReducer:
             # send nothing of this bucket early; reduce() picks the total up from .grad
             self._overlap_ok = False
             return grad
-        view = b.flat[o:o + n].view_as(param)
-        if grad.data_ptr() != view.data_ptr():
+        if grad is not view and grad.data_ptr() != vptr:
             view.copy_(grad)
         if view.is_cuda:
             b.streams.add(torch.cuda.current_stream())      # the engine finishes weight gradients on a side stream
@@ -149,7 +151,9 @@ class GradReducer:
         b.pending -= 1
         if b.pending == 0 and self._overlap_ok and self._layout_final:
             self._launch(b)
-        return view
+        # a FRESH alias: autograd's AccumulateGrad adopts an incoming gradient as .grad only when nobody else holds a reference to
+        # the tensor object; the cached view would be cloned instead (161 copies per ResNet-50 step, and as many back in reduce())
+        return view.detach()
 
     # ------------------------------------------------------------------ collectives
     def _launch(self, b):
@@ -195,8 +199,7 @@ class GradReducer:
                 continue
             # pack what the engine did not write in place: gradients that came through plain autograd, or every gradient when
             # this step could not overlap (accumulation into an existing .grad)
-            for p, o, n in b.items:
-                view = b.flat[o:o + n].view_as(p)
+            for (p, _, _), view in zip(b.items, b.views):
                 if p.grad is None:
                     view.zero_()
                 elif p.grad.data_ptr() != view.data_ptr():
@@ -205,12 +208,12 @@ class GradReducer:
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         for b in self.buckets:
-            for p, o, n in b.items:
-                view = b.flat[o:o + n].view_as(p)
-                if p.grad is None:
+            for (p, _, _), view in zip(b.items, b.views):
+                g = p.grad
+                if g is None:
                     p.grad = view.clone()
-                elif p.grad.data_ptr() != view.data_ptr():
-                    p.grad.copy_(view)
+                elif g is not view and g.data_ptr() != view.data_ptr():
+                    g.copy_(view)
         if self._attached and not self._layout_final and self._order:
             # first attached step done: lay the buckets out in the order the engine finishes gradients (everything the engine
             # never reported goes last, it is only available after backward anyway).  Old slices that .grad may still alias

@@ -4,6 +4,8 @@ ABI, against torch's CPU fp32 conv on the same bf16-rounded inputs (model/resnet
 Tolerance: inputs are pre-rounded to bf16, so the differences are fp32 accumulation order and the final bf16 rounding of the stored
 result: 1e-2 relative to max|ref| (the bound of tests/test_conv_kernels_gpu.py).  Bit tensors and masks are exact.
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -28,6 +30,10 @@ SHAPES = [
     (3, 21, 17, 192, 128, 3, 1, 1),     # three chunks
     (1, 150, 150, 128, 128, 3, 1, 1),   # wide image (the 150 x 150 decoder layers): 6-7 window blocks per wave, two stages, one workgroup per CU
     (1, 131, 97, 256, 128, 3, 1, 1),    # the same with four chunks, non-square
+    # the wide kernel (one wave per SIMD, round 4) is picked where all of its tiles are resident at once; the small shapes above take
+    # its 128-pixel form, these two its 192- and 256-pixel forms (the forced-mode test below runs every shape on every form)
+    (64, 19, 19, 256, 256, 3, 1, 1),    # ResNet-50 layer3 at the bench's size: 242 tiles of 192 px, 5 window blocks per wave
+    (40, 38, 38, 128, 128, 3, 1, 1),    # 226 tiles of 256 px, 7 window blocks per wave
     # 1x1: the persistent ring kernel (any contraction depth): (pixel tile, 64-channel chunk) steps over three LDS slots
     (2, 19, 19, 64, 256, 1, 1, 0),      # one chunk (an epilogue every step); data gradient: four chunks into 64 channels (2 x 2 waves)
     (3, 21, 17, 256, 64, 1, 1, 0),      # four chunks into 64 channels; data gradient: one chunk, 1 x 4 waves
@@ -42,6 +48,8 @@ SHAPES = [
     (40, 23, 23, 128, 64, 1, 1, 0),     # the same for the 2 x 2 wave layout, two chunks
     (1, 5, 5, 320, 128, 1, 1, 0),       # a single, partial pixel tile; five chunks
 ]
+if os.environ.get("CELLSEG_TEST_ONLY_3X3"):        # the forced-mode children of test_wide_kernel_forced_on_every_shape
+    SHAPES = [s for s in SHAPES if s[5] == 3]
 
 
 def _q(t):
@@ -271,3 +279,18 @@ def test_packed_kernels_are_exact_on_integer_data(shape, dev):
     for i in range(2):
         got = slabs[i].double().sum(0).float().cpu().permute(0, 3, 1, 2)     # [K][R][S][C] -> [K][C][R][S]
         assert torch.equal(got, ref_dw), f"wgrad item {i}: max diff {float((got - ref_dw).abs().max())}"
+
+
+def test_wide_kernel_forced_on_every_shape(dev):
+    """conv2_wide_kernel<TM, NBW> is picked by rule (csrc/conv_v2.hip: pick_wide_tm) for a few geometries only; CELLSEG_WIDE = 4 / 6 / 8
+    (A/B flavour of the library) forces that pixel-tile height wherever the window fits, = 1 switches the kernel off (the halo kernels
+    serve everything, as before round 4).  Every 3x3 shape of this file must pass the parity and the exact-integer tests on every form
+    (the knob is read once per process: child interpreters)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("1", "4", "6", "8"):
+        env = dict(os.environ, CELLSEG_WIDE=mode, CELLSEG_LIB_FLAVOUR="ab", CELLSEG_TEST_ONLY_3X3="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_packed_gpu.py"), "-m", "gpu", "-x", "-q",
+                            "-k", "packed_fwd_and_dgrad or exact_on_integer"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+        assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])

@@ -18,9 +18,12 @@ BUILD = os.path.join(ROOT, "cellsegmentation_amd", "csrc", "build")
 
 # source stem -> [(kernel-name substring, first owned VGPR)]; the limits are 2 x the amdgpu_num_vgpr of the kernel's declaration
 RULES = {
-    "conv_v2": [("conv2_halo_kernel", 100), ("conv2_ring_kernel", 96)],
+    "conv_v2": [("conv2_halo_kernel", 100), ("conv2_ring_kernel", 96), ("conv2_wide_kernel", 100)],
     "wgrad_v2": [("wgrad2_kernel", 82)],
 }
+
+
+AGPR_OWNED = 128      # first accumulation register an owned-register kernel may name (conv2_wide_kernel: a[128:255])
 
 
 def device_asm(stem):
@@ -64,6 +67,11 @@ def audit_text(text, rules):
         if not inasm:
             for mm in re.finditer(r"\bv\[?(\d+)(?::(\d+))?\]?", t):
                 if int(mm.group(2) or mm.group(1)) >= limit:
+                    st["bad"].append((i + 1, t))
+                    break
+            # accumulation registers: the wide kernel owns a[128:255]; hipcc may use LOW AGPRs as spill space for its own values
+            for mm in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", t):
+                if int(mm.group(2) or mm.group(1)) >= AGPR_OWNED:
                     st["bad"].append((i + 1, t))
                     break
     # kernel descriptors / metadata: private segment and spill counts

@@ -33,6 +33,9 @@ SHAPES = {
     "l3_3x3_s2": (64, 38, 38, 256, 256, 3, 2, 1),
     "l4_3x3_s2": (64, 19, 19, 512, 512, 3, 2, 1),
     "dec_3x3_2048_1024": (8, 19, 19, 2048, 1024, 3, 1, 1),
+    "dec_3x3_1024_512": (8, 38, 38, 1024, 512, 3, 1, 1),
+    "dec_3x3_512_256": (8, 75, 75, 512, 256, 3, 1, 1),
+    "dec_3x3_256_128": (8, 150, 150, 256, 128, 3, 1, 1),
     # EfficientNet-B3 1x1 products (expand / project): HBM-bound, odd channel counts
     "eff_exp_24_144_150": (64, 150, 150, 24, 144, 1, 1, 0),
     "eff_prj_144_32_75": (64, 75, 75, 144, 32, 1, 1, 0),
@@ -93,6 +96,8 @@ def main():
             torch.cuda.synchronize()
             ms = s0.elapsed_time(s1) / iters
             res[kind] = (ms, flops / ms / 1e9)
+            if os.environ.get("VARIANT"):
+                print(f"    {kind}: {(K._lib.load().cs_last_conv_variant() or b'').decode()}", flush=True)
         io_mb = (x.numel() + dy.numel()) * x.element_size() / 1e6
         print(f"{name:20s} " + "  ".join(f"{k}: {v[0] * 1e3:7.1f} us {v[1]:7.1f} TF" for k, v in res.items()) + f"   in+out {io_mb:6.1f} MB", flush=True)
 
