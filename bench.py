@@ -112,10 +112,13 @@ def kernel_name(kind, g, dtype):
     return g.get("variant") or "unknown"
 
 
-def _traffic_for(name, by_per_launch):
+def _traffic_for(name, by_per_launch, cfg=None):
     """HBM bytes per launch from the committed PMC passes (tools/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs,
-    gfx950-corrected), newest round first; None when the kernel was not sampled."""
-    for fn in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
+    gfx950-corrected), newest round first; None when the kernel was not sampled.  `cfg`: the passes of a secondary config
+    (tools/bench_configs.py c4 / c5 / c5x) instead of the headline step's."""
+    files = ([f"round{r}_traffic_{cfg}.json" for r in (4, 3)] if cfg
+             else ["round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"])
+    for fn in files:
         tpath = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(tpath):
             continue
@@ -130,7 +133,7 @@ def _traffic_for(name, by_per_launch):
     return None
 
 
-def roofline_from(records, steps, dtype):
+def roofline_from(records, steps, dtype, traffic_cfg=None):
     """Per-launch HIP-event times -> roofline of the dominant kernel instantiation (largest share of conv time) plus the dominant
     MFMA-bound and the dominant HBM-bound one.  A kernel's bound is decided by its aggregate arithmetic intensity against the
     machine balance: HBM-bound kernels are priced in algorithmic GB/s against the 8 TB/s spec, MFMA-bound ones in TFLOP/s
@@ -164,7 +167,7 @@ def roofline_from(records, steps, dtype):
             achieved, peak, unit, bound = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         else:
             achieved, peak, unit, bound = fl / (ms * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
-        tr = _traffic_for(name, by / n)
+        tr = _traffic_for(name, by / n, traffic_cfg)
         # `traffic`: HBM bytes per launch from the PMC passes (a plain number, or null); the read / write split rides beside it
         return {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
                 "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_detail": tr, "kernel": name, "avg_launch_ms": round(ms / n, 4), "launches": n,
@@ -358,6 +361,27 @@ def fp32_parity_mode_rate(dev, x, labels, steps=5, warmup=2):
             "note": "fp32 activations + v_mfma_f32_32x32x2_f32 (first-generation kernels); the mode of the 1e-4 parity tests"}
 
 
+def secondary_configs(timeout_s=240):
+    """N = 1 only, outside the timed region: short runs of the other BASELINE.json configs (C1 as one HIP graph, C4 EfficientNet-B3,
+    C5 segmentation at 299 and 512) in a CHILD process (tools/bench_configs.py: its own models and allocator; started, never exec'd),
+    so that the driver's record carries their throughput and the roofline of their dominant conv kernel next to the headline.
+    Never `value`."""
+    import subprocess
+    env = dict(os.environ, STEPS="6", ROOFLINE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c1", "c4", "c5", "c5x"], capture_output=True, text=True,
+                       timeout=timeout_s, env=env, cwd=ROOT)
+    out = []
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    if r.returncode != 0 and not out:
+        return {"error": (r.stderr or "")[-300:]}
+    return out
+
+
 def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
     """N = 1 only, outside the timed region: the same step with the gradient exchange switched ON over a one-rank RCCL
     communicator (`GradReducer(force_collectives=True)`: 32 MB flat buckets all-reduced from inside the HIP backward on a side
@@ -423,6 +447,7 @@ def main():
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
     ap.add_argument("--event-every", type=int, default=5, help="HIP-event-bracket the conv launches of every Nth timed step (1 = all)")
     ap.add_argument("--no-rccl-side", action="store_true", help="skip the one-rank RCCL side run (N=1)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs (N=1)")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-geometry launch table to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
@@ -523,6 +548,12 @@ def main():
                 rccl_side = rccl_world1_side(dev, model, params, opt, x, labels)
             except Exception as e:  # noqa: BLE001 -- a side number must never take the headline line down
                 rccl_side = {"error": f"{type(e).__name__}: {e}"[:300]}
+        secondary = None
+        if world == 1 and not args.no_secondary:
+            try:
+                secondary = secondary_configs()
+            except Exception as e:  # noqa: BLE001
+                secondary = {"error": f"{type(e).__name__}: {e}"[:300]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -550,6 +581,7 @@ def main():
             "cpu_baseline": cpu,
             "fp32_parity_mode": fp32_side,
             "rccl_world1": rccl_side,
+            "secondary": secondary,
         }
         print(json.dumps(out))
     if world > 1:

@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CELLSEG_LIB_FLAVOUR=ab: the A/B build (`make AB=1`: launch-rule knobs read from CELLSEG_* and cs_set_igemm_path compiled in).
 # Only the forced-mode tests and the tools/ sweeps set it, in child processes; the product loads the production library.
 FLAVOUR = os.environ.get("CELLSEG_LIB_FLAVOUR", "")
-if FLAVOUR not in ("", "ab"):
-    raise RuntimeError(f"CELLSEG_LIB_FLAVOUR={FLAVOUR!r}: expected unset or 'ab'")
-LIB_PATH = os.path.join(_HERE, "libcellseg_hip_ab.so" if FLAVOUR == "ab" else "libcellseg_hip.so")
+if FLAVOUR not in ("", "ab", "dbg"):
+    raise RuntimeError(f"CELLSEG_LIB_FLAVOUR={FLAVOUR!r}: expected unset, 'ab' or 'dbg' (`make DEBUG=1`: A/B switches + s_memtime stamps)")
+LIB_PATH = os.path.join(_HERE, f"libcellseg_hip_{FLAVOUR}.so" if FLAVOUR else "libcellseg_hip.so")
 
 CS_F32, CS_BF16 = 0, 1
 CS_ACT_NONE, CS_ACT_RELU, CS_ACT_SILU, CS_ACT_SIGMOID = 0, 1, 2, 3
@@ -162,7 +162,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, intentionally fatal
         fn.restype = restype
         fn.argtypes = argtypes
-    if FLAVOUR == "ab":
+    if FLAVOUR in ("ab", "dbg"):
         for name, (restype, argtypes) in _AB_SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = restype

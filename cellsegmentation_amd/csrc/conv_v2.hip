@@ -49,6 +49,9 @@ struct C2Params {
     unsigned n_tiles;              // 2-D: NS * tiles_y * tiles_x
     int stride;                    // 1x1 kernel only
     int gather, GH, GWp;           // ring forward of the pixel-paired stem (cs_stem_fwd_packed): LDS row = 32 gathered 16-byte (kh, pair) slots
+    unsigned tap_sh[9];            // wide kernel: LDS row shift of every tap of a stage (3x3: r * Wp + s; 1x1 on two planes: 0, BM)
+    int lin;                       // wide kernel, 1x1: the tile is a run of consecutive pixels, a stage holds TWO 64-channel planes
+    unsigned chunk_bytes;          // wide kernel: channel bytes a stage advances by (128; 256 with two planes)
     int add_stride, AH, AW;        // ring data gradient: the add operand is a COMPACT [NS][AH][AW][NOUT] tensor that only exists at destination
                                    // pixels (add_stride * y, add_stride * x) -- the gradient a strided 1x1 shortcut sends to the block input
     unsigned mg_dw, sh_dw, mg_dh, sh_dh, mg_wp, sh_wp, mg_hp, sh_hp;
@@ -461,13 +464,13 @@ template <int TM, bool PRE_RES, bool DG, typename TO = TileOffs> struct Epilogue
                 v[2 * k + 1] += hi;
             }
         }
-        if (!DG && p.act == CS_ACT_RELU) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        }
         unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        if (!DG && p.act == CS_ACT_RELU) {          // on the packed pairs: 8 instructions instead of 32 (cs_common.h relu_bf16x2)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pk[k] = relu_bf16x2(pk[k]);
+        }
         // groups (0,1) and (2,3): after the swaps lanes 0-31 hold channels 16j .. 16j+7, lanes 32-63 channels 16j+8 .. 16j+15
         swap32(pk[0], pk[2]); swap32(pk[1], pk[3]);
         swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
@@ -763,21 +766,21 @@ template <int A> __device__ __forceinline__ void addr1_w(unsigned q, unsigned sh
 // and fragment set s & 1; every MFMA is followed by the read that refills its fragment registers for step s + 2 (same tap) or for
 // steps 0 / 1 of the next tap (address set 1 - S).  The last tap of a chunk reads nothing ahead (the next stage is only visible
 // behind the barrier), the first starts cold.  NBW: 16-row LDS blocks this wave fetches per chunk, block j at step 2 * j.
-template <int TM, int NBW, int T, int NTAP, typename Pre>
+template <int TM, int NBW, int T, int NTAP, int NSLOT, int NB = 0, typename Pre>
 __device__ __forceinline__ void tap_wide(const unsigned (&qb)[TM], unsigned sh_cur, unsigned sh_next, unsigned hhs, unsigned cf0, Pre&& pre_step) {
     constexpr int S = T & 1;
     constexpr int A = W_AD + 8 * S, NA = W_AD + 8 * (1 - S);
     constexpr int F0 = W_AF, F1 = W_AF + 32;
     constexpr int W = 2 * TM - 1 < 15 ? 2 * TM - 1 : 15;
     constexpr bool COLD = T == 0, AHEAD = T != NTAP - 1;
-    pre_step.template operator()<4 * T + 0>();
+    pre_step.template operator()<NB + 4 * T + 0>();
     if constexpr (COLD) {
         for_n<TM>([&]<int i>() { addr1_w<A + i>(qb[i], sh_cur, hhs, cf0); });
         for_n<TM>([&]<int i>() { lds_rd<F0 + 4 * i, A + i, 0u>(); });
         for_n<TM>([&]<int i>() { lds_rd<F1 + 4 * i, A + i, 512u>(); });
     }
-    constexpr int B0 = W_B + 4 * ((4 * T + 0) % W_NSLOT), B1 = W_B + 4 * ((4 * T + 1) % W_NSLOT), B2 = W_B + 4 * ((4 * T + 2) % W_NSLOT),
-                  B3 = W_B + 4 * ((4 * T + 3) % W_NSLOT);
+    constexpr int B0 = W_B + 4 * ((NB + 4 * T + 0) % NSLOT), B1 = W_B + 4 * ((NB + 4 * T + 1) % NSLOT), B2 = W_B + 4 * ((NB + 4 * T + 2) % NSLOT),
+                  B3 = W_B + 4 * ((NB + 4 * T + 3) % NSLOT);
     // (the next tap's addresses -- 4 VALU per pixel tile -- ride in every other MFMA gap of steps 0 and 1: as one block in front of
     // the tap they would leave the matrix pipe idle for ~130 cycles)
     static_assert(TM % 2 == 0, "address interleave");
@@ -785,29 +788,37 @@ __device__ __forceinline__ void tap_wide(const unsigned (&qb)[TM], unsigned sh_c
         wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B0, F0 + 4 * i>(); lds_rd<F0 + 4 * i, A + i, 1024u>();
         if constexpr (AHEAD && i % 2 == 0) addr1_w<NA + i / 2>(qb[i / 2], sh_next, hhs, cf0);
     });
-    pre_step.template operator()<4 * T + 1>();
+    pre_step.template operator()<NB + 4 * T + 1>();
     for_n<TM>([&]<int i>() {
         wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B1, F1 + 4 * i>(); lds_rd<F1 + 4 * i, A + i, 1536u>();
         if constexpr (AHEAD && i % 2 == 0) addr1_w<NA + TM / 2 + i / 2>(qb[TM / 2 + i / 2], sh_next, hhs, cf0);
     });
-    pre_step.template operator()<4 * T + 2>();
+    pre_step.template operator()<NB + 4 * T + 2>();
     if constexpr (AHEAD) {
         for_n<TM>([&]<int i>() { wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B2, F0 + 4 * i>(); lds_rd<F0 + 4 * i, NA + i, 0u>(); });
-        pre_step.template operator()<4 * T + 3>();
+        pre_step.template operator()<NB + 4 * T + 3>();
         for_n<TM>([&]<int i>() { wait_lgkm<W>(); mfma_w<W_ACC + 16 * i, B3, F1 + 4 * i>(); lds_rd<F1 + 4 * i, NA + i, 512u>(); });
     } else {
         for_n<TM>([&]<int i>() { wait_lgkm<(2 * TM - 1 - i < 15 ? 2 * TM - 1 - i : 15)>(); mfma_w<W_ACC + 16 * i, B2, F0 + 4 * i>(); });
-        pre_step.template operator()<4 * T + 3>();
+        pre_step.template operator()<NB + 4 * T + 3>();
         for_n<TM>([&]<int i>() { wait_lgkm<TM - 1 - i>(); mfma_w<W_ACC + 16 * i, B3, F1 + 4 * i>(); });
     }
 }
 
-template <int TM, int NBW, bool DG>
+// NTAP = 9: the 3x3 stride-1 convolutions (a stage = the halo window of one 64-channel chunk).  NTAP = 2 (round 4): the
+// DEEP 1x1 convolutions -- no halo, a stage holds two 64-channel planes of the tile's own pixel rows and the "taps" are the planes
+// (row shift 0 / BM), so a barrier comes every 8 * TM MFMA; the weight ring has 8 slots there (8 steps per stage) and all DMA pieces of
+// a stage are issued in front of its first step.
+template <int TM, int NBW, bool DG, int NTAP = 9>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(50))) void conv2_wide_kernel(C2Params p) {
     static_assert(TM >= 2 && TM <= 8 && NBW >= 1 && NBW <= 9, "register map / DMA schedule");
-    constexpr int NTAP = 9, SK = 3, NSTEP = 4 * NTAP;
-    static_assert(NSTEP % W_NSLOT == 0, "slot numbers must repeat from chunk to chunk");
-    static_assert(2 * (NBW - 1) < NSTEP - (W_NSLOT - 1), "every DMA piece of a chunk must be older than the weights of its last step");
+    constexpr int NSTEP = 4 * NTAP;
+    // weight ring: 18 slots over the 36 steps of a 3x3 stage; 16 slots over TWO 8-step stages of the 1x1 form (the loop body is
+    // unrolled twice so that slot numbers stay compile-time constants)
+    constexpr int NSLOT = NTAP == 9 ? W_NSLOT : 16;
+    static_assert(NSLOT <= W_NSLOT && (NTAP == 9 ? NSTEP % NSLOT == 0 : NSLOT == 2 * NSTEP), "weight ring");
+    static_assert(NTAP != 9 || 2 * (NBW - 1) < NSTEP - (NSLOT - 1), "every DMA piece of a stage must be older than the weights of its last step");
+    static_assert(NTAP == 9 || (NTAP == 2 && NBW <= 8), "tap tables exist for 3x3 and for the two-plane 1x1 (one DMA block per step)");
     constexpr int BM = TM * 32, BN = 128;
     constexpr unsigned STAGE = NBW * 4 * 2048;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -829,7 +840,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(50))) void c
     Epilogue<TM, false, DG, TileOffs> epi(p, m0, n_w, mtile, alive, 0u);
     unsigned qb[TM];
     unsigned voff[NBW];
-    {
+    if constexpr (NTAP == 2) {
+        // 1x1: LDS row r of plane pl = pixel m0 + r, channels [128 * stage + 64 * pl, + 64); block b = wave + 4j holds rows 16b .. 16b + 15
+        // of the stage's 2 * BM rows
+#pragma unroll
+        for (int i = 0; i < TM; ++i) qb[i] = 32u * i + (unsigned)l31;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const unsigned r2 = 16u * (unsigned)(wave + 4 * j) + (unsigned)(lane & 15);
+            const unsigned pl = r2 >= (unsigned)BM ? 1u : 0u, r = r2 - pl * (unsigned)BM;
+            const unsigned m = m0 + r;
+            voff[j] = (r2 < 2u * BM && m < p.M) ? m * p.pix_bytes + pl * 128u + (unsigned)(lane >> 4) * 16u : OOB;
+        }
+    } else {
         auto pos0 = [&](unsigned m) -> unsigned {      // padded-linear position of tap offset (0,0) of destination pixel m
             const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
             const unsigned x = m - yall * (unsigned)p.DW;
@@ -860,59 +883,124 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(50))) void c
     const i32x4 rsrc_a = make_rsrc(p.src, p.src_bytes);
     const i32x4 rsrc_b = make_rsrc(p.wpk, p.wpk_bytes);
     const unsigned bvoff = alive ? (unsigned)lane * 16u : OOB;
-    unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)p.NCC * (unsigned)(NTAP * 4096);
+    // (NCC = 64-channel chunks of the contraction; a stage multiplies NTAP * 64 deep: 9 taps of one chunk, or two chunks)
+    unsigned wsoff = (unsigned)(n_w >> 5) * (unsigned)p.NCC * (unsigned)((NTAP == 9 ? 9 : 1) * 4096);
     const unsigned smem_base = lds_off(smem);
+    const int NSTAGE = NTAP == 9 ? p.NCC : p.NCC / 2;
 
+#ifdef CS_DEBUG_V2
+    // diagnostic build: shader-clock stamps around the phases + the constant 100 MHz counter at both ends (in-kernel clock =
+    // delta s_memtime / delta s_memrealtime x 100 MHz); marker 3 = wide kernel (tools/stamp_probe.py)
+    unsigned long long w_t[4], w_rt[2];
+#define CS_WSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w_t[i]))
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w_rt[0]));
+    CS_WSTAMP(0);
+#else
+#define CS_WSTAMP(i)
+#endif
     epi.prefetch();
     asm volatile("; v[100:255] and a[128:255] are owned by the main loop" ::: "v100", "v255", "a128", "a255");
     for_n<16 * TM>([&]<int r>() { azero<W_ACC + r>(); });
     const unsigned cf0 = 0xf0u;
 
-    // ---- prologue: chunk 0 of the operand rows, weights of steps 0 .. 16
+    if constexpr (NTAP == 9) {
+        // ---- prologue: chunk 0 of the operand rows, weights of steps 0 .. 16
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) dma_block(rsrc_a, smem_base + (unsigned)(wave + 4 * j) * 2048u, voff[j], 0u);
-    for_n<W_NSLOT - 1>([&]<int k>() { bload1<k>(rsrc_b, bvoff, wsoff); wsoff += 1024u; });
-    wait_vm<W_NSLOT - 1>();
-    raw_barrier();
-
-    const int NCC = p.NCC;
-    for (int cc = 0; cc < NCC; ++cc) {
-        const unsigned cur = (cc & 1) ? STAGE : 0u, nxt = STAGE - cur;
-        const unsigned hhs = (unsigned)hh * 256u + cur;
-        const bool more = cc + 1 < NCC;
-        const unsigned nxt_soff = (unsigned)(cc + 1) * 128u;
-        // in front of the MFMAs of step n: refill the slot step n - 1 has just released with the weights of step n + 17, send this
-        // step's share of the next chunk's rows, then wait until the weights of step n have landed (17 younger loads + the DMA
-        // pieces issued since then stay in flight)
-        auto pre_step = [&]<int n>() {
-            bload1<(n + W_NSLOT - 1) % W_NSLOT>(rsrc_b, bvoff, wsoff);
-            wsoff += 1024u;
-            if constexpr (n % 2 == 0 && n / 2 < NBW) {
-                constexpr int j = n / 2;
-                dma_block(rsrc_a, smem_base + nxt + (unsigned)(wave + 4 * j) * 2048u, more ? voff[j] : OOB, nxt_soff);
-            }
-            constexpr int lo = n - (W_NSLOT - 1) > 0 ? n - (W_NSLOT - 1) : 0;
-            constexpr int first = (lo + 1) / 2, last = n / 2 < NBW - 1 ? n / 2 : NBW - 1;       // blocks j with lo <= 2j <= n
-            constexpr int pieces = last >= first ? 2 * (last - first + 1) : 0;
-            wait_vm<W_NSLOT - 1 + pieces>();
-        };
-        for_n<NTAP>([&]<int T>() {
-            const unsigned sh_cur = (unsigned)(T / SK) * (unsigned)p.LW + (unsigned)(T % SK);
-            const unsigned sh_next = (unsigned)((T + 1) / SK) * (unsigned)p.LW + (unsigned)((T + 1) % SK);
-            tap_wide<TM, NBW, T, NTAP>(qb, sh_cur, sh_next, hhs, cf0, pre_step);
-        });
-        // every wave's pieces of the next chunk have landed (the wait of step 35 is younger than all of them) and this stage is read out
+        for (int j = 0; j < NBW; ++j) dma_block(rsrc_a, smem_base + (unsigned)(wave + 4 * j) * 2048u, voff[j], 0u);
+        for_n<NSLOT - 1>([&]<int k>() { bload1<k>(rsrc_b, bvoff, wsoff); wsoff += 1024u; });
+        wait_vm<NSLOT - 1>();
         raw_barrier();
-        if (!more) epi.scr = smem_base + nxt + (unsigned)wave * EPI_WAVE;
+        CS_WSTAMP(1);
+
+        for (int cc = 0; cc < NSTAGE; ++cc) {
+            const unsigned cur = (cc & 1) ? STAGE : 0u, nxt = STAGE - cur;
+            const unsigned hhs = (unsigned)hh * 256u + cur;
+            const bool more = cc + 1 < NSTAGE;
+            const unsigned nxt_soff = (unsigned)(cc + 1) * p.chunk_bytes;
+            // in front of the MFMAs of step n: refill the slot step n - 1 has just released with the weights of step n + 17, send this
+            // step's share of the next chunk's rows, then wait until the weights of step n have landed (17 younger loads + the DMA
+            // pieces issued since then stay in flight)
+            auto pre_step = [&]<int n>() {
+                bload1<(n + NSLOT - 1) % NSLOT>(rsrc_b, bvoff, wsoff);
+                wsoff += 1024u;
+                if constexpr (n % 2 == 0 && n / 2 < NBW) {
+                    constexpr int j = n / 2;
+                    dma_block(rsrc_a, smem_base + nxt + (unsigned)(wave + 4 * j) * 2048u, more ? voff[j] : OOB, nxt_soff);
+                }
+                constexpr int lo = n - (NSLOT - 1) > 0 ? n - (NSLOT - 1) : 0;
+                constexpr int first = (lo + 1) / 2, last = n / 2 < NBW - 1 ? n / 2 : NBW - 1;       // blocks j with lo <= 2j <= n
+                constexpr int pieces = last >= first ? 2 * (last - first + 1) : 0;
+                wait_vm<NSLOT - 1 + pieces>();
+            };
+            for_n<NTAP>([&]<int T>() {
+                tap_wide<TM, NBW, T, NTAP, NSLOT>(qb, p.tap_sh[T], p.tap_sh[T + 1 < NTAP ? T + 1 : T], hhs, cf0, pre_step);
+            });
+            // every wave's pieces of the next chunk have landed (the wait of step 35 is younger than all of them) and this stage is read out
+            raw_barrier();
+            if (!more) epi.scr = smem_base + nxt + (unsigned)wave * EPI_WAVE;
+        }
+    } else {
+        // ---- 1x1 on two-plane stages.  THREE LDS stages: the rows of stage s + 2 are sent during stage s, one 16-row block per step
+        // (a burst of 2 * NBW DMA instructions in front of a stage kept the matrix pipe idle for ~2000 cycles: stamps, round 4), and
+        // the weights of step g + 15 in front of step g.  In issue order, behind the weights of step g there are always 15 younger
+        // loads and the 2 * NBW blocks of two stages' worth of steps: vmcnt(15 + 4 * NBW) -- except at a stage's last step, which
+        // must also see the rows of the NEXT stage (sent during the previous one) land before the barrier hands them over: behind
+        // the last of those only 16 - NBW loads and this stage's 2 * NBW pieces are younger.  The prologue replays the issue
+        // pattern of two virtual stages (-2: rows of stage 0, -1: rows of stage 1) so that the immediates hold from step 0 on.
+        for_n<16>([&]<int k>() {
+            if constexpr (k >= 1) { bload1<k - 1>(rsrc_b, bvoff, wsoff); wsoff += 1024u; }
+            if constexpr (k % 8 < NBW) {
+                constexpr int j = k % 8, st = k / 8;
+                dma_block(rsrc_a, smem_base + (unsigned)st * STAGE + (unsigned)(wave + 4 * j) * 2048u, (st < NSTAGE) ? voff[j] : OOB, (unsigned)st * p.chunk_bytes);
+            }
+        });
+        wait_vm<16 + NBW>();
+        raw_barrier();
+        CS_WSTAMP(1);
+        unsigned cur = 0u, dst = 2u * STAGE;             // LDS stage being multiplied / being filled (two stages ahead)
+        auto stage = [&]<int NB>(int cc) {
+            const unsigned hhs = (unsigned)hh * 256u + cur;
+            const bool more2 = cc + 2 < NSTAGE;
+            const unsigned soff2 = (unsigned)(cc + 2) * p.chunk_bytes;
+            auto pre_step = [&]<int n>() {
+                constexpr int l = n - NB;
+                bload1<(n + NSLOT - 1) % NSLOT>(rsrc_b, bvoff, wsoff);
+                wsoff += 1024u;
+                if constexpr (l < NBW) dma_block(rsrc_a, smem_base + dst + (unsigned)(wave + 4 * l) * 2048u, more2 ? voff[l] : OOB, soff2);
+                wait_vm<(l == 7 ? 16 + NBW : 15 + 4 * NBW)>();
+            };
+            for_n<NTAP>([&]<int T>() {
+                tap_wide<TM, NBW, T, NTAP, NSLOT, NB>(qb, p.tap_sh[T], p.tap_sh[T + 1 < NTAP ? T + 1 : T], hhs, cf0, pre_step);
+            });
+            raw_barrier();
+            cur = cur == 2u * STAGE ? 0u : cur + STAGE;
+            dst = dst == 2u * STAGE ? 0u : dst + STAGE;
+        };
+        for (int cc = 0; cc < NSTAGE; cc += 2) {        // (the plan admits an even number of stages only)
+            stage.template operator()<0>(cc);
+            stage.template operator()<8>(cc + 1);
+        }
+        wait_vm<0>();                                    // the out-of-range tail pieces write zeros: gone before the scratch is used
+        raw_barrier();
+        epi.scr = smem_base + (unsigned)wave * EPI_WAVE;
     }
     // MFMA results -> VALU reads: the last MFMA needs its 16 passes (no hardware interlock on this path)
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7");
+    CS_WSTAMP(2);
     for_n<TM>([&]<int i>() {
         const f32x16 d = acc_read_w<i>();
         epi.template operator()<i>(d);
     });
     epi.finish();
     wait_vm<0>();                     // the out-of-range tail loads are gone before the registers / LDS are released
+#ifdef CS_DEBUG_V2
+    CS_WSTAMP(3);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w_rt[1]));
+    if (p.dbg && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
+        o[0] = 3; o[1] = w_t[1] - w_t[0]; o[2] = w_t[2] - w_t[1]; o[3] = w_t[3] - w_t[2]; o[4] = w_t[3] - w_t[0]; o[5] = w_rt[1] - w_rt[0];
+    }
+#endif
 }
 
 // =================================================================================================
@@ -1054,13 +1142,13 @@ template <int TM, bool DG> struct RingEpilogue {
                 v[2 * k + 1] += hi;
             }
         }
-        if (!DG && p.act == CS_ACT_RELU) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        }
         unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        if (!DG && p.act == CS_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pk[k] = relu_bf16x2(pk[k]);
+        }
         swap32(pk[0], pk[2]); swap32(pk[1], pk[3]);
         swap32(pk[4], pk[6]); swap32(pk[5], pk[7]);
         CS_ETICK(0);
@@ -1410,6 +1498,24 @@ int pick_tm(long long M, int n_ntiles) {
     return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
 }
 
+// The same decision for the deep 1x1 convolutions (wide kernel on two-plane stages, cfg 8).  CELLSEG_WIDE1 (A/B flavour): 1 = never,
+// 4 / 6 / 8 = force that height.  Only where the ring kernel is chain-bound: >= 8 chunks (512 contraction channels), all tiles resident
+// at once; the short contractions into wide outputs stay on the ring kernel (HBM-bound, many pixel tiles per workgroup).
+int pick_wide1_tm(long long M, int n_ntiles, int ncc) {
+    static const int knob = cs_env_int_("CELLSEG_WIDE1", 0);
+    if (knob == 1) return 0;
+    if (knob == 4 || knob == 6) return knob;
+    if (ncc < 8) return 0;
+    int best = 0;
+    long long best_cost = 1ll << 60, best_tiles = 0;
+    for (int tm = 6; tm >= 4; tm -= 2) {               // (three LDS stages: 3 x 8 KiB x tm per wave column -- 144 KiB at tm = 6)
+        const long long tiles = ((M + 32 * tm - 1) / (32 * tm)) * n_ntiles;
+        const long long cost = ((tiles + 255) / 256) * tm;
+        if (cost < best_cost) { best_cost = cost; best = tm; best_tiles = tiles; }
+    }
+    return best_tiles <= 256 ? best : 0;
+}
+
 const bool g_v2_off = cs_env_flag_("CELLSEG_NO_V2");     // A/B flavour only
 
 bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
@@ -1466,6 +1572,8 @@ bool plan_halo(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     p.Wp = Wp; p.Hp = Hp; p.PW = PWH; p.PH = PWH;
     p.stride = 1;
     p.LW = t2d ? 16 + g->S - 1 : Wp;
+    for (int t = 0; t < 9; ++t) p.tap_sh[t] = (unsigned)((t / 3) * p.LW + t % 3);
+    p.chunk_bytes = 128u;
     magic((unsigned)DW, p.mg_dw, p.sh_dw);
     magic((unsigned)DH, p.mg_dh, p.sh_dh);
     magic((unsigned)p.LW, p.mg_wp, p.sh_wp);
@@ -1519,7 +1627,7 @@ int pick_ring_tm(long long M, int n_ntiles, int ncc) {
     return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
 }
 
-bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
+bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl, bool allow_wide = true) {
     if (g_v2_off) return false;
     if (g->groups > 1) return false;
     if (g->R != 1 || g->S != 1 || g->pad != 0 || g->stride < 1) return false;
@@ -1568,6 +1676,16 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     pl.cfg = cfg; pl.nbw = 0; pl.ncc = ncc;
     pl.tm = cfg == 6 ? pick_ring_tm(M, p.n_ntiles, ncc) : 2;
     pl.rows = cfg == 6 ? cs_ceil_div(M, 32 * pl.tm) : cs_ceil_div(M, 128) * 2;
+    pl.t2d = 0;
+    if (cfg == 6 && allow_wide && p.stride == 1 && !compact && ncc % 4 == 0) {      // (two chunks per stage, two stages per loop body)
+        const int wtm = pick_wide1_tm(M, p.n_ntiles, ncc);
+        if (wtm) {
+            pl.cfg = 8; pl.tm = wtm; pl.nbw = wtm;          // 2 planes x 32 * tm rows = 4 * tm blocks of 16 rows, tm per wave
+            pl.rows = cs_ceil_div(M, 32 * wtm);
+            p.lin = 1; p.chunk_bytes = 256u;
+            p.tap_sh[0] = 0u; p.tap_sh[1] = 32u * (unsigned)wtm;
+        }
+    }
     return true;
 }
 
@@ -1605,9 +1723,15 @@ int launch_ring_t(const C2Params& p, hipStream_t st) {
     return CS_OK;
 }
 
+template <int TM, int NBW, bool DG, int NTAP = 9> int launch_wide(const C2Params& p, hipStream_t st);
+
 template <bool DG>
 int launch_gemm(const C2Plan& pl, hipStream_t st) {
     const C2Params& p = pl.p;
+    if (pl.cfg == 8) {
+        if (pl.tm == 4) return launch_wide<4, 4, DG, 2>(p, st);
+        return launch_wide<6, 6, DG, 2>(p, st);
+    }
     if (pl.cfg == 6) {
         if (pl.tm == 2) return launch_ring_t<2, 1, 4, DG>(p, st);
         if (pl.tm == 3) return launch_ring_t<3, 1, 4, DG>(p, st);
@@ -1632,15 +1756,15 @@ int launch_cfg1(const C2Params& p, hipStream_t st, int two_stage) {
     return CS_OK;
 }
 
-template <int TM, int NBW, bool DG>
+template <int TM, int NBW, bool DG, int NTAP>
 int launch_wide(const C2Params& p, hipStream_t st) {
     const unsigned n_mt = (unsigned)cs_ceil_div(p.M, 32 * TM);
     dim3 grid(((n_mt + 7) / 8) * 8 * (unsigned)p.n_ntiles);
-    const size_t lds = (size_t)NBW * 8192 * 2;           // two stages; the epilogue's exchange scratch borrows the idle one
-    auto fn = conv2_wide_kernel<TM, NBW, DG>;
+    const size_t lds = (size_t)NBW * 8192 * (NTAP == 9 ? 2 : 3);      // two stages (1x1 form: three); the epilogue's exchange scratch borrows an idle one
+    auto fn = conv2_wide_kernel<TM, NBW, DG, NTAP>;
     if (!allow_lds(fn, lds)) return CS_ERR_LAUNCH;
     char name[64];
-    snprintf(name, sizeof(name), "conv2_wide_kernel<%d,%d,%s>", TM, NBW, DG ? "true" : "false");
+    snprintf(name, sizeof(name), "conv2_wide_kernel<%d,%d,%s,%d>", TM, NBW, DG ? "true" : "false", NTAP);
     cs_set_variant_(name);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
     CS_LAUNCH_CHECK();
@@ -1767,7 +1891,8 @@ extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const
         CS_CHECK_ARG(!add && !mask_bits && !partial_rows,
                      "conv2d_dgrad_packed: a strided 1x1 data gradient is written in compact [N][P][Q][C] form, without add / mask / column sums");
     if (add_stride == 2) {
-        CS_CHECK_ARG(pl.cfg >= 6 && pl.p.DH >= 2 && pl.p.DW >= 2, "conv2d_dgrad_packed: a strided add operand is served by the 1x1 (ring) kernel only");
+        if (pl.cfg == 8 && !plan_gemm(g, 1, pl, false)) return CS_ERR_UNSUPPORTED;          // the compact add operand is a ring-kernel feature
+        CS_CHECK_ARG(pl.cfg >= 6 && pl.cfg <= 7 && pl.p.DH >= 2 && pl.p.DW >= 2, "conv2d_dgrad_packed: a strided add operand is served by the 1x1 (ring) kernel only");
         pl.p.add_stride = 2;
         pl.p.AH = (pl.p.DH + 1) / 2;
         pl.p.AW = (pl.p.DW + 1) / 2;

@@ -50,11 +50,19 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
-    union { bf16_t h[2]; uint32_t u; } cv;
-    cv.h[0] = (bf16_t)lo;
-    cv.h[1] = (bf16_t)hi;
-    return cv.u;
+    // ONE v_cvt_pk_bf16_f32 (RNE, NaN stays NaN).  Written as asm: from two plain casts hipcc (ROCm 7.2) emits the instruction once
+    // PER VALUE with a dummy second source and glues the halves with a shift and an SDWA or -- four instructions per pair, 32 per
+    // 32 x 32 accumulator tile in every convolution epilogue (seen in the .s of conv_v2.hip, round 4).
+    uint32_t u;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u) : "v"(lo), "v"(hi));
+    return u;
+}
+// ReLU of two packed bf16 values: the sign bit of a bf16 is the sign bit of its int16 pattern, so max(x, 0) as signed 16-bit integers
+// clears negative values (and -0.0) and keeps positive ones -- the same result as rounding max(x, 0.f), one instruction per pair.
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t x) {
+    uint32_t u;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(x));
+    return u;
 }
 
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);

@@ -209,7 +209,7 @@ def _stats_ws(M, n_out, device):
 def set_igemm_path(path):
     """0 = LDS-DMA staging (default), 1 = register staging, 3 = LDS-DMA + experimental streaming kernel. Returns the previous value.
     A/B flavour of the library only (CELLSEG_LIB_FLAVOUR=ab, `make AB=1`): the production library has no such switch."""
-    if _lib.FLAVOUR != "ab":
+    if _lib.FLAVOUR not in ("ab", "dbg"):
         raise RuntimeError("set_igemm_path: the production library has no A/B switches; run with CELLSEG_LIB_FLAVOUR=ab")
     return _lib.load().cs_set_igemm_path(int(path))
 

@@ -62,12 +62,31 @@ class GradReducer:
         self._overlap_ok = True    # this step: gradients may be reduced from inside backward
         self._slot = {}            # id(param) -> (bucket, offset, numel)
         self.launches_in_backward = 0     # buckets sent before reduce() in the last step (diagnostics / tests)
+        self.n_rest_buckets = 0           # buckets holding parameters the engine never reports (they can only go in reduce())
         self._timed = []
         self._build(list(reversed(self.params)))       # reverse order ~ the order gradients become ready
 
     # ------------------------------------------------------------------ layout
-    def _build(self, ordered):
+    def _build(self, ordered, taper=False, n_engine=None):
+        """Cut `ordered` (parameters in the order their gradients become ready) into buckets of at most `bucket_bytes`.
+        taper: the LAST buckets are small (1/16, 1/8, 1/4, 1/2 of `bucket_bytes` from the end) -- whatever is still on the wire when
+        backward ends is exposed, and the stem / first-stage gradients that finish last are a few hundred KiB, so the tail that
+        cannot overlap shrinks from a full bucket to ~2 MB at the price of three more (small) collectives.  n_engine: only the
+        first n_engine parameters are reported by the engine during backward (the taper is theirs); the rest -- gradients that plain
+        autograd produces, parameters that get none -- can only go in reduce() and sit in buckets of their own behind them."""
         self.buckets, self._slot = [], {}
+        sizes = [(p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for p in ordered]
+        n_engine = len(ordered) if n_engine is None else n_engine
+        cuts = {n_engine} if 0 < n_engine < len(ordered) else set()          # indices i: a bucket ends before parameter i
+        if taper and n_engine > 1:
+            caps = [self.bucket_bytes // 16, self.bucket_bytes // 8, self.bucket_bytes // 4, self.bucket_bytes // 2]
+            i, acc, ci = n_engine - 1, 0, 0
+            while i > 0 and ci < len(caps):
+                acc += sizes[i] * 4
+                if acc >= caps[ci]:
+                    cuts.add(i)
+                    acc, ci = 0, ci + 1
+                i -= 1
         cur, cur_n = [], 0
 
         def close():
@@ -79,15 +98,16 @@ class GradReducer:
                 self._slot[id(p)] = (b, view, view.data_ptr())
             self.buckets.append(b)
 
-        for p in ordered:
+        for i, p in enumerate(ordered):
             n = p.numel()
-            if cur and (cur_n + n) * 4 > self.bucket_bytes:
+            if cur and ((cur_n + n) * 4 > self.bucket_bytes or i in cuts):
                 close()
                 cur, cur_n = [], 0
             cur.append((p, cur_n, n))
-            cur_n += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+            cur_n += sizes[i]
         if cur:
             close()
+        self.n_rest_buckets = sum(1 for b in self.buckets if any(id(p) not in self._order_ids for p, _, _ in b.items)) if self._order_ids else 0
         self._begin_step()
 
     def _begin_step(self):
@@ -220,7 +240,7 @@ class GradReducer:
             # stay alive through those tensors; the next zero_grad() drops them.
             rest = [p for p in reversed(self.params) if id(p) not in self._order_ids]
             self._layout_final = True
-            self._build(self._order + rest)
+            self._build(self._order + rest, taper=True, n_engine=len(self._order))
         else:
             self._begin_step()
         self.launches_in_backward = sent_early

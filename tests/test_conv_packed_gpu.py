@@ -48,8 +48,8 @@ SHAPES = [
     (40, 23, 23, 128, 64, 1, 1, 0),     # the same for the 2 x 2 wave layout, two chunks
     (1, 5, 5, 320, 128, 1, 1, 0),       # a single, partial pixel tile; five chunks
 ]
-if os.environ.get("CELLSEG_TEST_ONLY_3X3"):        # the forced-mode children of test_wide_kernel_forced_on_every_shape
-    SHAPES = [s for s in SHAPES if s[5] == 3]
+if os.environ.get("CELLSEG_TEST_ONLY_3X3"):        # the forced-mode children of test_wide_kernel_forced_on_every_shape: what the wide kernel can serve
+    SHAPES = [s for s in SHAPES if s[5] == 3 or (s[5] == 1 and s[6] == 1 and (s[3] >= 512 or s[4] >= 512))]
 
 
 def _q(t):
@@ -290,7 +290,8 @@ def test_wide_kernel_forced_on_every_shape(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("1", "4", "6", "8"):
-        env = dict(os.environ, CELLSEG_WIDE=mode, CELLSEG_LIB_FLAVOUR="ab", CELLSEG_TEST_ONLY_3X3="1")
+        # (CELLSEG_WIDE1: the same switch for the wide kernel's two-plane 1x1 form, served where the contraction has >= 8 chunks)
+        env = dict(os.environ, CELLSEG_WIDE=mode, CELLSEG_WIDE1=mode, CELLSEG_LIB_FLAVOUR="ab", CELLSEG_TEST_ONLY_3X3="1")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_packed_gpu.py"), "-m", "gpu", "-x", "-q",
                             "-k", "packed_fwd_and_dgrad or exact_on_integer"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])

@@ -74,7 +74,7 @@ def _worker_body(rank, world, port, q):
             worst = max(worst, float((p.grad - e).abs().max() / (e.abs().max() + 1e-12)))
     red.detach()
     torch.cuda.synchronize()
-    q.put((rank, worst, early, len(red.buckets)))
+    q.put((rank, worst, early, len(red.buckets) - red.n_rest_buckets + 1))      # (+1: the historical "all but the head's bucket")
     dist.destroy_process_group()
 
 

@@ -41,7 +41,7 @@ def fill(m):
     return m.to(dev)
 
 
-def run(name, step, n, unit):
+def run(name, step, n, unit, roofline_cfg=None):
     for _ in range(WARM):
         step()
     torch.cuda.synchronize()
@@ -50,7 +50,23 @@ def run(name, step, n, unit):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / STEPS
-    print(json.dumps({"config": name, "value": round(n / dt, 1), "unit": unit, "ms_per_step": round(dt * 1e3, 3)}), flush=True)
+    line = {"config": name, "value": round(n / dt, 1), "unit": unit, "ms_per_step": round(dt * 1e3, 3)}
+    if roofline_cfg and os.environ.get("ROOFLINE"):
+        # the dominant conv-family kernel of this config: per-launch HIP events over three more (eager) steps, priced exactly as
+        # bench.py prices the headline's; `traffic` from this config's own PMC passes (profiles/round*_traffic_<cfg>.json)
+        from bench import roofline_from
+        from cellsegmentation_amd import kernels as KK
+        timer = KK.LaunchTimer()
+        with timer:
+            timer.enabled = True
+            for _ in range(3):
+                step()
+        torch.cuda.synchronize()
+        roof = roofline_from(timer.results(), 3, torch.bfloat16, traffic_cfg=roofline_cfg)
+        if roof:
+            line["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches", "share_of_conv_time")}
+            line["conv3x3_family_frac_of_mfma_peak"] = roof.get("conv3x3_family_frac_of_mfma_peak")
+    print(json.dumps(line), flush=True)
 
 
 def tiles(n, size=299, seed=1234):
@@ -114,7 +130,7 @@ if "c4" in which:
         opt.zero_grad(set_to_none=True)
         HF.cross_entropy(m(x, freeze_bn=True), y).backward()
         opt.step()
-    run("c4 efficientnet_b3 tile bag=64 bf16 (fwd+bwd+Adam, BN train)", s4, 64, "tiles/s")
+    run("c4 efficientnet_b3 tile bag=64 bf16 (fwd+bwd+Adam, BN train)", s4, 64, "tiles/s", roofline_cfg="c4")
     # roofline entry of C4's dominant kernel family (profiles/round3_efficientnet_b3_kernel_stats.md: bn_bwd_reduce_kernel + bn_bwd_apply_kernel,
     # 78 train-mode BatchNorms): HIP events around every BN backward of three more steps; algorithmic bytes = the reduction reads dy and z,
     # the apply pass reads them again and writes dz: 5 passes over an M x C bf16 tensor; HBM-bound by construction
@@ -178,7 +194,7 @@ if "c5" in which:
         opt.zero_grad(set_to_none=True)
         HF.dice_loss(HF.softmax_channel(m(x), 1), mask).backward()
         opt.step()
-    run("c5 resnet50 segment B=8 299x299 bf16 (decoder training, Dice)", s5, 8, "images/s")
+    run("c5 resnet50 segment B=8 299x299 bf16 (decoder training, Dice)", s5, 8, "images/s", roofline_cfg="c5")
 if "c5x" in which:
     m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
     x = tiles(4, 512); mask = (torch.rand(4, 512, 512, device=dev) > 0.8).float()
@@ -188,7 +204,7 @@ if "c5x" in which:
         opt.zero_grad(set_to_none=True)
         HF.dice_loss(HF.softmax_channel(m(x), 1), mask).backward()
         opt.step()
-    run("c5x resnet50 segment B=4 512x512 bf16 (decoder training, Dice)", s5x, 4, "images/s")
+    run("c5x resnet50 segment B=4 512x512 bf16 (decoder training, Dice)", s5x, 4, "images/s", roofline_cfg="c5x")
 if "c1cpu" in which:
     # the oracle is test infrastructure: it runs inside bench.py's cpu_baseline leg only
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -31,6 +31,15 @@ for name in sys.argv[1:] or ["l1_3x3", "l2_3x3", "l3_3x3", "l4_3x3"]:
     lib.cs_debug_set_stamp_buffer(None)
     b = buf.cpu().reshape(-1, 6)
     b = b[b[:, 0] != 0].double()
+    if float(b[:, 0].max()) == 3.0:           # wide kernel: phase lengths in shader cycles + the 100 MHz counter over the wave's life
+        clk = b[:, 4] / b[:, 5] * 0.1
+        ntm = int(os.environ.get("CELLSEG_WIDE", "0")) or 0
+        print(f"{name}: waves {len(b)}; in-kernel clock med {clk.median():.3f} GHz (p10 {clk.quantile(0.1):.3f}, p90 {clk.quantile(0.9):.3f}); wave life med "
+              f"{b[:, 4].median():.0f} cycles = {(b[:, 5].median() / 100):.2f} us; MFMA cycles of the loop = {(C // 64) * R * R * 4 * 32} x TM")
+        for n_, col in zip(["index math + first loads + barrier", "main loop", "epilogue + drain"], (1, 2, 3)):
+            v = b[:, col]
+            print(f"    {n_:36s} med {v.median():8.0f}   p10 {v.quantile(0.1):8.0f}   p90 {v.quantile(0.9):8.0f}")
+        continue
     if float(b[:, 0].max()) == 2.0:           # ring kernel: per-phase sums over the workgroup's steps
         packed = b[:, 5].long()
         nt, ns = (packed & 0xffffffff).double(), (packed >> 32).double()
