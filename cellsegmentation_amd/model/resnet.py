@@ -280,7 +280,10 @@ class MILResNet(nn.Module):
     def forward(self, x, freeze_bn=False):
         if self.mode == "tile" and freeze_bn:
             (x4,) = self._trunk(x, False, False)
-            self.train()                          # the reference's eval()/train() flip (resnet.py:256-258)
+            # the reference's eval()/train() flip (resnet.py:256-258) leaves EVERY module in train mode.  nn.Module.train() walks the
+            # ~200 modules with a __setattr__ each (0.8 ms of host time per step, profiles/round4_notes.md): only when one is not
+            if not self._all_training():
+                self.train()
         elif self.mode == "segment":
             x4, x3, x2, x1 = self._trunk(x, self.training, True)
         else:
@@ -299,6 +302,21 @@ class MILResNet(nn.Module):
             return HF.to_nchw(o, 2)
         else:
             raise Exception("Something wrong in setmode.")
+
+
+def _all_training(self):
+    mods = self.__dict__.get("_module_list")
+    if mods is None or len(mods) != self.__dict__.get("_module_count", -1):
+        mods = list(self.modules())
+        self.__dict__["_module_list"] = mods
+        self.__dict__["_module_count"] = len(mods)
+    for m in mods:
+        if not m.training:
+            return False
+    return True
+
+
+MILResNet._all_training = _all_training
 
 
 def _make(name, pretrained, **kwargs):

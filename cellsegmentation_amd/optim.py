@@ -58,15 +58,17 @@ class Adam(torch.optim.Optimizer):
         heads) go to different launches -- one per (step count, <= cs_adam_max_tensors tensors) -- as torch.optim.Adam's
         per-parameter step allows.  Plans are cached per (parameter set, class pattern), so alternating sets do not re-plan."""
         lib = _lib.load()
-        key = (gi, tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in plist),
-               classes)
+        # (the moments are this class's own tensors, replaced in load_state_dict only -- which drops the plans; a parameter's storage
+        # can be replaced from outside, e.g. module.to(device) after the optimizer was built, so its address is part of the key)
+        key = (gi, tuple([p.data_ptr() for p in plist]), classes)
         cached = self._plans.get(key)
         if cached is not None:
             return cached
         dev = plist[0].device
         chunk, cap = lib.cs_adam_chunk_elems(), lib.cs_adam_max_tensors()
         order = sorted(range(len(plist)), key=lambda i: classes[i])            # stable: members of a class stay in parameter order
-        table = torch.tensor([list(key[1][i]) for i in order], dtype=torch.int64).to(dev)          # CsAdamTensor[] (p, m, v, n)
+        rows = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in plist]
+        table = torch.tensor([list(rows[i]) for i in order], dtype=torch.int64).to(dev)          # CsAdamTensor[] (p, m, v, n)
         launches, t0 = [], 0
         while t0 < len(order):
             t1 = t0
@@ -98,10 +100,15 @@ class Adam(torch.optim.Optimizer):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
                 continue
+            state = self.state
             for p in plist:
-                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                if p not in state or len(state[p]) == 0:      # first step of this parameter: validate once, then trust the plan key
+                    if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.is_sparse:
+                        raise RuntimeError("cellsegmentation_amd.optim.Adam: contiguous fp32 CUDA parameters with dense fp32 gradients only")
+                    self._init_state(p)
+                g = p.grad
+                if g.dtype != torch.float32 or g.is_sparse:
                     raise RuntimeError("cellsegmentation_amd.optim.Adam: contiguous fp32 CUDA parameters with dense fp32 gradients only")
-                self._init_state(p)
             beta1, beta2 = group["betas"]
             hs = [self._host_step(p) for p in plist]
             seen = {}
