@@ -407,13 +407,32 @@ template <int TM, bool PRE_RES, bool DG, typename TO = TileOffs> struct Epilogue
         return scr + (unsigned)(lane & 31) * EPI_ROW + (unsigned)(2 * j + (lane >> 5)) * 16u;
     }
 
+    // byte offset of the residual / add operand's row for (32-pixel tile i, half q): the destination row itself, or -- compact strided
+    // operand of a data gradient (add_stride = 2, see RingEpilogue::add_off; the wide kernel's 1x1 form serves such layers too) -- the
+    // row of pixel (y / 2, x / 2) when both coordinates are even, nothing otherwise
+    __device__ __forceinline__ unsigned res_off(int i, int q) const {
+        if constexpr (TO::kPreset) return to.row(p.M, (unsigned)p.NOUT, i, q);
+        else {
+            if (p.add_stride <= 1) return to.row(p.M, (unsigned)p.NOUT, i, q);
+            const unsigned lane = threadIdx.x & 63;
+            const unsigned m = to.mr + 16u * (unsigned)(2 * i + q);
+            const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
+            const unsigned x = m - yall * (unsigned)p.DW;
+            const unsigned n = udivm(yall, p.mg_dh, p.sh_dh);
+            const unsigned y = yall - n * (unsigned)p.DH;
+            const unsigned mc = (n * (unsigned)p.AH + (y >> 1)) * (unsigned)p.AW + (x >> 1);
+            return (m < p.M && !((x | y) & 1u)) ? (mc * (unsigned)p.NOUT + (unsigned)n_w + 8u * (lane & 3u)) * 2u : OOB;
+        }
+    }
+
     __device__ __forceinline__ void prefetch() {
         const int lane = threadIdx.x & 63;
         const int hh = lane >> 5;
         const unsigned out_bytes = p.M * (unsigned)p.NOUT * 2u;
         if constexpr (!TO::kPreset) to.set(m0w, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
         r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
-        r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, p.residual ? out_bytes : 0u, 0x00020000);
+        r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0,
+                                                  !p.residual ? 0u : p.add_stride == 2 ? (unsigned)(p.NS * p.AH * p.AW * p.NOUT) * 2u : out_bytes, 0x00020000);
         r_bin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.bits_in), 0, p.bits_in ? out_bytes >> 4 : 0u, 0x00020000);
         r_bout = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? out_bytes >> 4 : 0u, 0x00020000);
 #pragma unroll
@@ -426,8 +445,8 @@ template <int TM, bool PRE_RES, bool DG, typename TO = TileOffs> struct Epilogue
         for (int i = 0; i < TM; ++i) {
             // a NULL operand has a zero-sized buffer: the loads return zeros without touching memory
             if constexpr (PRE_RES) {
-                rr[i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, i, 0), 0, 0));
-                rr[i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, i, 1), 0, 0));
+                rr[i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, res_off(i, 0), 0, 0));
+                rr[i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, res_off(i, 1), 0, 0));
             }
             if constexpr (DG) mb[i] = __builtin_amdgcn_raw_buffer_load_b32(r_bin, to.bit(p.M, (unsigned)p.NOUT, i), 0, 0);
         }
@@ -444,8 +463,8 @@ template <int TM, bool PRE_RES, bool DG, typename TO = TileOffs> struct Epilogue
             uint4 x0, x1;
             if constexpr (PRE_RES) { x0 = rr[I][0]; x1 = rr[I][1]; }
             else {
-                x0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, I, 0), 0, 0));
-                x1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, to.row(p.M, (unsigned)p.NOUT, I, 1), 0, 0));
+                x0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, res_off(I, 0), 0, 0));
+                x1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r_res, res_off(I, 1), 0, 0));
             }
             lds_put(row_lds(0), x0);
             lds_put(row_lds(1), x1);
@@ -1082,13 +1101,18 @@ template <int TM, bool DG> struct RingEpilogue {
     template <int I> __device__ __forceinline__ void arm(const TileOffs& t) {
         const unsigned v0 = add_off(t, I, 0), v1 = add_off(t, I, 1);
         const unsigned lds = __builtin_amdgcn_readfirstlane(region + (unsigned)I * 2048u);
+#ifdef CS_EXPERIMENT_NT
+#define CS_RES_POLICY " nt"
+#else
+#define CS_RES_POLICY ""
+#endif
         asm volatile(
             "s_mov_b32 m0, %0\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+            "buffer_load_dwordx4 %1, %3, 0 offen" CS_RES_POLICY " lds\n\t"
             "s_add_u32 m0, %0, 0x400\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %2, %3, 0 offen lds"
+            "buffer_load_dwordx4 %2, %3, 0 offen" CS_RES_POLICY " lds"
             ::"s"(lds), "v"(v0), "v"(v1), "s"(q_res)
             : "memory", "scc");
         if constexpr (DG) {
@@ -1891,8 +1915,8 @@ extern "C" int cs_conv2d_dgrad_packed(const CsConvGeom* g, const void* dy, const
         CS_CHECK_ARG(!add && !mask_bits && !partial_rows,
                      "conv2d_dgrad_packed: a strided 1x1 data gradient is written in compact [N][P][Q][C] form, without add / mask / column sums");
     if (add_stride == 2) {
-        if (pl.cfg == 8 && !plan_gemm(g, 1, pl, false)) return CS_ERR_UNSUPPORTED;          // the compact add operand is a ring-kernel feature
-        CS_CHECK_ARG(pl.cfg >= 6 && pl.cfg <= 7 && pl.p.DH >= 2 && pl.p.DW >= 2, "conv2d_dgrad_packed: a strided add operand is served by the 1x1 (ring) kernel only");
+        // (the SAME plan as cs_conv2d_packed_partial_rows reported: the caller sized the column-sum rows by it)
+        CS_CHECK_ARG(pl.cfg >= 6 && pl.p.DH >= 2 && pl.p.DW >= 2, "conv2d_dgrad_packed: a strided add operand is served by the 1x1 kernels only");
         pl.p.add_stride = 2;
         pl.p.AH = (pl.p.DH + 1) / 2;
         pl.p.AW = (pl.p.DW + 1) / 2;

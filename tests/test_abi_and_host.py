@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib._AB_SIGNATURES) == ab_only
     for name in ab_only:
         assert not hasattr(lib, name), f"{name} is an A/B switch: it must not be exported by the production library"
-    assert lib.cs_abi_version() >= 3
+    assert lib.cs_abi_version() >= 5
 
 
 def test_production_library_reads_no_environment():

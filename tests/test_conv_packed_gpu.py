@@ -148,7 +148,9 @@ def test_packed_declines_what_it_does_not_serve(dev):
         K.conv_fwd_packed(geom, x, torch.zeros((16,), dtype=BF, device=dev))
 
 
-@pytest.mark.parametrize("shape", [(2, 37, 41, 256, 128, 64), (3, 20, 20, 128, 256, 128), (64, 10, 10, 512, 1024, 256), (1, 7, 9, 64, 64, 64)])
+# (the last shape: conv1 of layer4.0 -- 8 chunks into 1024 channels, served by the wide kernel's 1x1 form; it must take the compact operand too)
+@pytest.mark.parametrize("shape", [(2, 37, 41, 256, 128, 64), (3, 20, 20, 128, 256, 128), (64, 10, 10, 512, 1024, 256), (1, 7, 9, 64, 64, 64),
+                                   (2, 19, 19, 1024, 2048, 512)])
 def test_compact_strided_gradient(shape, dev):
     """The block input of a down-sampling bottleneck (model/resnet.py:183 + :51) receives two gradients: the stride-2 1x1 shortcut's
     (non-zero at even pixels only) and the stride-1 conv1's.  The shortcut's data gradient is written in compact [N][P][Q][C] form and

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel roofline tables of C4 (EfficientNet-B3 tile step) and C5 (ResNet-50 segmentation step) from the committed rocprofv3
-kernel statistics and PMC traffic of this round -> profiles/round3_roofline_c4_c5.md.
+kernel statistics and PMC traffic of this round -> profiles/round<N>_roofline_c4_c5.md.
 
     python tools/roofline_c4_c5.py
 
@@ -13,6 +13,8 @@ import math
 import os
 import re
 import sys
+
+ROUND = int(__import__("os").environ.get("ROUND", "4"))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -107,10 +109,10 @@ def main():
            "peak: HBM 8000 GB/s (spec; ~6300 achievable), dense bf16 MFMA 2500 TFLOP/s.  `achieved` = algorithmic bytes (or FLOPs) per step / "
            "kernel time per step from the rocprofv3 table; `traffic` = HBM bytes per step from the FETCH_SIZE / WRITE_SIZE passes (read side x2).", ""]
     # ---------------- C4
-    tab, tr = stats(os.path.join(P, "round3_bench_kernel_stats.csv"), 25), None
+    tab, tr = stats(os.path.join(P, f"round{ROUND}_bench_kernel_stats.csv"), 25), None
     tab = stats(os.path.join(ROOT, "gpurun_out", "round", "prof_c4", "p_kernel_stats.csv"), 12) if os.path.exists(
         os.path.join(ROOT, "gpurun_out", "round", "prof_c4", "p_kernel_stats.csv")) else {}
-    tr = traffic(os.path.join(P, "round3_traffic_c4.json"))
+    tr = traffic(os.path.join(P, f"round{ROUND}_traffic_c4.json"))
     bn, dw_in, dw_out, pw = b3_tensors()
     total = sum(v[1] for v in tab.values())
     out += [f"## C4: EfficientNet-B3 tile bag 64 bf16, BN train (GPU time {total:.2f} ms/step)", "",
@@ -138,8 +140,8 @@ def main():
     out += ["", f"(1x1 products: {2 * 2 * 1.666e9 * 64 / 1e9:.0f} GFLOP fwd + dgrad per step = "
             f"{2 * 2 * 1.666e9 * 64 / (find_ms(tab, r'^igemm_dma_kernel|^igemm_kernel') * 1e-3) / 1e12:.0f} TFLOP/s: not a matrix-core problem)", ""]
     # ---------------- C5
-    for tag, csvname, trname, n, hw, title in (("c5", "prof_c5", "round3_traffic_c5.json", 8, 299, "C5: ResNet-50 segmentation B=8 299x299 bf16 (decoder training)"),
-                                              ("c5x", "prof_c5x", "round3_traffic_c5x.json", 4, 512, "C5: the same at 512x512 B=4")):
+    for tag, csvname, trname, n, hw, title in (("c5", "prof_c5", f"round{ROUND}_traffic_c5.json", 8, 299, "C5: ResNet-50 segmentation B=8 299x299 bf16 (decoder training)"),
+                                              ("c5x", "prof_c5x", f"round{ROUND}_traffic_c5x.json", 4, 512, "C5: the same at 512x512 B=4")):
         pth = os.path.join(ROOT, "gpurun_out", "round", csvname, "p_kernel_stats.csv")
         if not os.path.exists(pth):
             continue
@@ -180,7 +182,7 @@ def main():
         c, ms, tb = summed(tab, tr, r"^adam_multi")
         out.append(f"adam_multi_kernel: {ms:.3f} ms/step, counter traffic {tb / 1e9:.2f} GB/step ({tb / (ms * 1e-3) / 1e9:.0f} GB/s).")
         out.append("")
-    open(os.path.join(P, "round3_roofline_c4_c5.md"), "w").write("\n".join(out) + "\n")
+    open(os.path.join(P, f"round{ROUND}_roofline_c4_c5.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
 
