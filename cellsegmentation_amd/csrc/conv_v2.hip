@@ -1101,18 +1101,15 @@ template <int TM, bool DG> struct RingEpilogue {
     template <int I> __device__ __forceinline__ void arm(const TileOffs& t) {
         const unsigned v0 = add_off(t, I, 0), v1 = add_off(t, I, 1);
         const unsigned lds = __builtin_amdgcn_readfirstlane(region + (unsigned)I * 2048u);
-#ifdef CS_EXPERIMENT_NT
-#define CS_RES_POLICY " nt"
-#else
-#define CS_RES_POLICY ""
-#endif
+        // (round 4: the `nt` cache policy on these two loads -- the operand is read once -- measured equal on layer1 and 25-35 % slower
+        // on layer2-4, where the residual is still in the Infinity Cache from the launch that wrote it: default policy)
         asm volatile(
             "s_mov_b32 m0, %0\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %1, %3, 0 offen" CS_RES_POLICY " lds\n\t"
+            "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
             "s_add_u32 m0, %0, 0x400\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %2, %3, 0 offen" CS_RES_POLICY " lds"
+            "buffer_load_dwordx4 %2, %3, 0 offen lds"
             ::"s"(lds), "v"(v0), "v"(v1), "s"(q_res)
             : "memory", "scc");
         if constexpr (DG) {

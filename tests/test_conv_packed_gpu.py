@@ -297,3 +297,56 @@ def test_wide_kernel_forced_on_every_shape(dev):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_packed_gpu.py"), "-m", "gpu", "-x", "-q",
                             "-k", "packed_fwd_and_dgrad or exact_on_integer"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
+
+
+def _resnet_geometries():
+    """(H, Cin, Cout, R) of every stride-1 packed convolution of the ResNet-50 / ResNet-18 trunks and the decoder."""
+    out = []
+    for H, w in ((75, 64), (38, 128), (19, 256), (10, 512)):
+        out += [(H, w, w, 3), (H, w, 4 * w, 1), (H, 4 * w, w, 1)]
+        if w > 64:
+            out += [(2 * H - (1 if H in (38, 10) else 0), 2 * w, w, 1)]      # conv1 of a down-sampling block (input of the previous stage)
+    out += [(19, 2048, 1024, 3), (38, 1024, 512, 3)]
+    return out
+
+
+@pytest.mark.parametrize("N", [1, 3, 16, 40])
+def test_packed_kernels_agree_with_the_first_generation_over_the_resnet_family(N, dev):
+    """Routing depends on the number of tiles (halo / wide 3x3 / ring / wide 1x1, pixel-tile heights), i.e. on the bag size: every
+    stride-1 packed geometry of the ResNet family at four bag sizes, forward and data gradient (with the add operand -- dense, and compact
+    where the layer is conv1 of a down-sampling block --, mask bits and column sums), against the first-generation kernels on the same
+    device tensors.  The folded column sums must equal the sums of the stored gradient: a launch that writes other partial rows than
+    cs_conv2d_packed_partial_rows reported (the round-4 fault of the wide 1x1 form with a compact operand) cannot pass."""
+    g = torch.Generator().manual_seed(5 + N)
+    for H, Cin, Cout, R in _resnet_geometries():
+        if N * H * H * max(Cin, Cout) > 64 * 75 * 75 * 256:
+            continue
+        geom = K.make_geom(N, H, H, Cin, Cout, R, R, 1, R // 2)
+        if not K.packed_supported(geom, BF, dgrad=False):
+            continue
+        x = torch.randn((N, H, H, Cin), generator=g).to(BF).to(dev)
+        w = torch.randn((Cout, Cin, R, R), generator=g) / (Cin * R * R) ** 0.5
+        w_khwc, w_chwk = K.weight_prep(w.to(dev), None, BF, Cin, Cout, want_fwd=True, want_bwd=True)
+        y = K.conv_fwd_packed(geom, x, K.pack_conv_weights(geom, w_khwc, dgrad=False))
+        y0 = K.conv_fwd(geom, x, w_khwc)
+        torch.cuda.synchronize()
+        assert _relerr(y.float().cpu(), y0.float().cpu()) < TOL, (N, H, Cin, Cout, R, "fwd")
+        if not K.packed_supported(geom, BF, dgrad=True):
+            continue
+        dy = torch.randn((N, H, H, Cout), generator=g).to(BF).to(dev)
+        mask = (torch.rand((N, H, H, Cin), generator=g) > 0.4)
+        bits = _pack_bits(mask.permute(0, 3, 1, 2), dev)
+        wpd = K.pack_conv_weights(geom, w_chwk, dgrad=True)
+        adds = [torch.randn((N, H, H, Cin), generator=g).to(BF).to(dev)]
+        if R == 1 and H >= 2:
+            adds.append(K.CompactGrad(torch.randn((N, (H + 1) // 2, (H + 1) // 2, Cin), generator=g).to(BF).to(dev), 2))
+        for add in adds:
+            dense = add
+            if isinstance(add, K.CompactGrad):
+                dense = torch.zeros((N, H, H, Cin), dtype=BF, device=dev)
+                dense[:, ::2, ::2, :] = add.t
+            dx, pc = K.conv_dgrad_packed(geom, dy, wpd, add=add, mask_bits=bits, want_colsum=True)
+            dx0 = K.conv_dgrad(geom, dy, w_chwk, add=dense, mask_bits=bits)
+            torch.cuda.synchronize()
+            assert _relerr(dx.float().cpu(), dx0.float().cpu()) < TOL, (N, H, Cin, Cout, R, "dgrad", type(add).__name__)
+            assert _relerr(pc.vector().cpu(), dx.float().sum(dim=(0, 1, 2)).cpu()) < 2e-3, (N, H, Cin, Cout, R, "colsum", pc.rows)

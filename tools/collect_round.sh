@@ -10,9 +10,9 @@ mkdir -p $O
 python bench.py --steps 20 --warmup 5 --per-layer > $O/bench.json 2> $O/per_layer.txt || exit 1
 echo "bench done"; head -c 200 $O/bench.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-side > $O/bench_profiled.json 2> /dev/null || exit 1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-launch-timing > /dev/null 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-launch-timing > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-side --no-secondary --no-rccl-side > $O/bench_profiled.json 2> /dev/null || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-secondary --no-rccl-side --no-launch-timing > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-secondary --no-rccl-side --no-launch-timing > /dev/null 2>&1 || exit 1
 echo "bench profiles done"
 for cfg in c4 c5 c5x; do
   STEPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -o p -- python3 $R/tools/bench_configs.py $cfg > $O/$cfg.log 2>&1 || exit 1
