@@ -453,6 +453,12 @@ def main():
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to stdout when a communicator is created, child
+    # processes and libraries may print too -- file descriptor 1 points at stderr until the line itself is written
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -583,7 +589,10 @@ def main():
             "rccl_world1": rccl_side,
             "secondary": secondary,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -152,7 +152,7 @@ class GradReducer:
         s = self._slot.get(id(param))
         if s is None or not self._active:
             return grad
-        if id(param) not in self._order_ids:
+        if not self._layout_final and id(param) not in self._order_ids:
             self._order_ids.add(id(param))
             self._order.append(param)
         b, view, vptr = s
@@ -165,8 +165,8 @@ class GradReducer:
             return grad
         if grad is not view and grad.data_ptr() != vptr:
             view.copy_(grad)
-        if view.is_cuda:
-            b.streams.add(torch.cuda.current_stream())      # the engine finishes weight gradients on a side stream
+        if _engine.WGRAD_SIDE_STREAM and view.is_cuda:
+            b.streams.add(torch.cuda.current_stream())      # (opt-in engine mode: weight gradients finished on a side stream)
         self._delivered.add(id(param))
         b.pending -= 1
         if b.pending == 0 and self._overlap_ok and self._layout_final:
@@ -227,8 +227,11 @@ class GradReducer:
             self._launch(b)
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+        inplace = self._delivered if self._overlap_ok else ()          # gradients autograd adopted as an alias of their bucket slice
         for b in self.buckets:
             for (p, _, _), view in zip(b.items, b.views):
+                if id(p) in inplace:
+                    continue
                 g = p.grad
                 if g is None:
                     p.grad = view.clone()

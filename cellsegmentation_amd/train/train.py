@@ -131,3 +131,45 @@ def train_seg(loader, epoch, total_epochs, model, device, optimizer, scheduler):
     if not (scheduler is None or _per_step(scheduler)):
         scheduler.step()
     return float(acc.item()) / len(loader.dataset)
+
+
+def train_alternative(loader, epoch, total_epochs, model, device, crit_cls, crit_reg, optimizer, scheduler, threshold, alpha, beta,
+                      gamma, delta):
+    """Alternating tile / image training for one epoch (train/train.py:210-300; no driver of the reference calls it).  Per batch
+    `(data, labels)` with data = (images, tiles) and labels = (image class, image count, tile label): a TILE step (setmode("tile"),
+    plain forward -- the reference passes no freeze_bn here --, loss gamma * crit_cls) and an IMAGE step (setmode("image"),
+    alpha * crit_cls + beta * crit_reg) on ONE optimizer, zero_grad in between: the encoder is updated by both, each head by its own
+    step (cellsegmentation_amd.optim.Adam keeps a step count per parameter, as torch.optim.Adam does).  `threshold` and `delta`
+    are unused by the reference too (its segmentation part is commented out).  Returns
+    (tile_loss, image_cls_loss, image_reg_loss, image_seg_loss = 0.0, image_loss)."""
+    tile_num = 0
+    acc = torch.zeros((4,), device=device)          # tile, image cls, image reg, image total (weighted by batch sizes)
+    for i, (data, labels) in enumerate(tqdm(loader, desc="alternative training")):
+        # pt.1: tile training
+        model.setmode("tile")
+        model.train()
+        optimizer.zero_grad()
+        output = model(data[1].to(device))
+        tile_loss_i = _ce(crit_cls, output, labels[2].to(device), gamma)
+        tile_loss_i.backward()
+        optimizer.step()
+        tile_num += data[1].size(0)
+        # pt.2: image training
+        model.setmode("image")
+        model.train()
+        optimizer.zero_grad()
+        output = model(data[0].to(device))
+        l_cls = _ce(crit_cls, output[0], labels[0].to(device))
+        l_reg = _mse(crit_reg, output[1].squeeze(), labels[1].to(device, dtype=torch.float32))
+        image_loss_i = alpha * l_cls + beta * l_reg
+        image_loss_i.backward()
+        optimizer.step()
+        if _per_step(scheduler):
+            scheduler.step()
+        nt, ni = data[1].size(0), data[0].size(0)
+        acc += torch.stack([tile_loss_i.detach() * nt, l_cls.detach() * ni, l_reg.detach() * ni, image_loss_i.detach() * ni])
+    if not (scheduler is None or _per_step(scheduler)):
+        scheduler.step()
+    t, c, r, tot = acc.tolist()
+    n = len(loader.dataset)
+    return t / max(1, tile_num), c / n, r / n, 0.0, tot / n

@@ -132,6 +132,36 @@ def test_train_seg_step_matches_oracle(dev):
     assert out.shape == (n, size, size) and float(np.abs(out - ref.numpy()).max()) < 1e-4
 
 
+def test_train_alternative_matches_oracle(dev):
+    """train/train.py:210-300: a tile step and an image step per batch on ONE optimizer.  Losses against the oracle (train-mode BN in both
+    steps: the reference passes no freeze_bn there), and the per-parameter step counts of the one-launch HIP Adam after the epoch: the
+    tile head and the image heads step once per batch, the encoder only in image steps (setmode("tile") freezes it)."""
+    import torch.nn.functional as F
+    from cellsegmentation_amd.optim import Adam
+    arch, n = "resnet18", 4
+    xi = synth.normalise(synth.ihc_tiles(n, 64, 61))
+    xt = synth.normalise(synth.ihc_tiles(2 * n, 32, 62))
+    counts = torch.tensor([0, 3, 12, 40])
+    cls = torch.tensor([orc.categorize(int(c)) for c in counts])
+    yt = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    m = _model(arch, dev)
+    m.setmode("image")
+    m.set_tile_module_grads(True)
+    opt = Adam([p for p in m.parameters() if p.requires_grad], lr=0.0)        # lr 0: the second batch sees the same weights
+    batches = [((xi, xt), (cls, counts, yt))] * 2
+    tl, cl, rl, sl, il = T.train_alternative(_Loader(batches, 2 * n, n), 1, 1, m, dev, torch.nn.CrossEntropyLoss(), torch.nn.MSELoss(), opt, None,
+                                             0.5, 1.0, 2.0, 0.7, 0.0)
+    sd = _oracle_sd(arch, lambda k: False)
+    want_t = 0.7 * F.cross_entropy(orc.forward(sd, xt, arch, "tile", training=True), yt).item()
+    oc, orr, _ = orc.image_step_loss(_oracle_sd(arch, lambda k: False), xi, cls, counts, arch)
+    assert abs(tl - want_t) < 2e-4 * abs(want_t)
+    assert abs(cl - oc.item()) < 2e-4 * abs(oc.item()) and abs(rl - orr.item()) < 2e-4 * abs(orr.item())
+    assert sl == 0.0 and abs(il - (1.0 * oc.item() + 2.0 * orr.item())) < 2e-4 * abs(il)
+    steps = {k: float(opt.state[p]["step"]) for k, p in m.named_parameters() if p in opt.state and len(opt.state[p])}
+    assert steps["fc_tile.1.weight"] == 2.0 and steps["fc_image_cls.7.weight"] == 2.0 and steps["layer1.0.conv1.weight"] == 2.0
+    assert m.mode == "image"
+
+
 def test_loss_modules_match_reference_vectors(dev):
     a, b = torch.from_numpy(GOLD["loss/dice_in"]).to(dev), torch.from_numpy(GOLD["loss/dice_tg"]).to(dev)
     assert abs(T.DiceLoss()(a, b).item() - float(GOLD["loss/dice_mean"])) < 1e-5
