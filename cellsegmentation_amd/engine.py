@@ -186,6 +186,8 @@ def _packed_flags(plan, u, geom, dtype, need_bwd, batch_stats, bits, bn_train=Fa
         # z is written first and one cs_bn_stats pass reads it back.  Only where that pass is noise next to the MFMA work: dense
         # stride-1 3x3 convolutions of >= 128 channels (the segmentation decoder, resnet.py:195-200 -- 86 % of segment-mode FLOPs).
         # Their ReLU masks, where no bit plane exists, are made on demand in backward (kernels.positive_bits).
+        # (Round 4 tried the forward-only 1x1 convolutions of the frozen encoder too -- 21 us launches at 0.08 of HBM on the
+        # first-generation kernel at B = 8: with the ring kernel + the statistics pass C5 went 1454 -> 1407 img/s, 512 x 512 580 -> 562.)
         if not (PACKED_TRAIN_BN and geom.R == 3 and geom.S == 3 and geom.stride == 1 and min(geom.C, geom.K) >= 128):
             return False, False
         pkf = K.packed_supported(geom, dtype, dgrad=False)
