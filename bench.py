@@ -24,7 +24,8 @@ def _self_launch():
     (`python -m torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1) and exit with its return code.  This runs
     before torch / the HIP library are imported, so the parent never touches the GPU (no exec after GPU init, no second HIP
     context beside the ranks).  The reference's counterpart is the DDP stub of train_tile.py:227-238."""
-    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+    # under torchrun (RANK is set for every rank) this process IS a rank; a bare WORLD_SIZE=1 some schedulers pre-export is not torchrun
+    if "RANK" in os.environ or ("WORLD_SIZE" in os.environ and os.environ["WORLD_SIZE"] != "1"):
         return
     n = 1
     argv = sys.argv[1:]
@@ -35,16 +36,15 @@ def _self_launch():
             n = int(a.split("=", 1)[1])
     if n <= 1:
         return
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr=127.0.0.1",
-           f"--master-port={port}", os.path.abspath(__file__), *argv]
+    # --standalone: torchrun picks a free rendezvous port itself (probing one here and handing it over is a race);
+    # --local-addr because the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr=127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__), *argv]
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 

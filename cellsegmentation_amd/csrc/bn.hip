@@ -410,7 +410,11 @@ extern "C" int cs_bn_partial_fold(const double* partial, int rows, int C, double
 extern "C" size_t cs_bn_partial_workspace(long long M, int C) {
     if (M <= 0 || C <= 0) return 0;
     const int rpb = rows_per_block_for(M, C);
-    return (size_t)((M + rpb - 1) / rpb) * 2 * (size_t)C * sizeof(double);
+    const long long blocks = (M + rpb - 1) / rpb;
+    // 0 = no workspace wanted: with this few workgroups cs_bn_stats / cs_bn_bwd_reduce add their sums with fp64 atomics (the ONE place
+    // the rule lives: callers allocate what this function says)
+    if (blocks <= kBnAtomicBlocks) return 0;
+    return (size_t)blocks * 2 * (size_t)C * sizeof(double);
 }
 
 extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream) {

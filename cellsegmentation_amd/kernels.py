@@ -618,10 +618,12 @@ def bn_stats(z, stats=None):
 
 
 def _bn_ws(M, C, device):
-    """Partial-sum workspace of the BN reductions (None for small row counts: a few workgroups, atomics are fine)."""
-    if M < 2048:
+    """Partial-sum workspace of the BN reductions, or None where the library wants none (cs_bn_partial_workspace returns 0: few
+    workgroups, fp64 atomics -- nearly every layer; the decision is the library's alone)."""
+    nbytes = _lib.load().cs_bn_partial_workspace(M, C)
+    if nbytes == 0:
         return None
-    return torch.empty((_lib.load().cs_bn_partial_workspace(M, C) // 8,), dtype=torch.float64, device=device)
+    return torch.empty((nbytes // 8,), dtype=torch.float64, device=device)
 
 
 def bn_finalize(stats, M, eps, momentum, running_mean=None, running_var=None):

@@ -67,7 +67,8 @@ int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const f
  * BatchNorm1d of the image heads, resnet.py:134,138) over NHWC rows z[M][C] ----------------------
  * stats: fp64 [2][C] (sum, sum of squares), zeroed by the caller; also filled by cs_conv2d_fwd. */
 int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream);
-/* `workspace` of cs_bn_stats / cs_bn_bwd_reduce (nullable, cs_bn_partial_workspace(M, C) bytes): per-workgroup partial sums are
+/* `workspace` of cs_bn_stats / cs_bn_bwd_reduce (nullable, cs_bn_partial_workspace(M, C) bytes -- 0 where the launch has so few
+ * workgroups that it adds its sums with fp64 atomics and wants none): per-workgroup partial sums are
  * written there and folded by a second small launch instead of ~1000 fp64 atomics per channel (3x faster on large tensors). */
 size_t cs_bn_partial_workspace(long long M, int C);
 /* mean, rstd = 1/sqrt(biased var+eps); running_* (nullable) updated in place with `momentum` and the

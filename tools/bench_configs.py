@@ -101,6 +101,29 @@ if "c1" in which:
     gstep = GraphedStep(s1g_body, (x, cls, counts.float()))
     cf = counts.float()
     run("c1g same step as one HIP graph (GraphedStep)", lambda: gstep(x, cls, cf), 8, "images/s")
+if "c2g" in which:
+    # the headline step (bench.py: ResNet-50 tile, trainable trunk, freeze_bn) eager and as one HIP graph: how much of the step is launch gaps / host
+    from cellsegmentation_amd.graphed import GraphedStep
+    m = fill(R.MILresnet50()); m.setmode("tile"); m.set_encoder_grads(True); m.train()
+    x = tiles(64); y = torch.tensor([(i * 7 + 1) % 2 for i in range(64)], device=dev)
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
+
+    def s2e():
+        opt.zero_grad(set_to_none=True)
+        HF.cross_entropy(m(x, freeze_bn=True), y).backward()
+        opt.step()
+    run("c2 resnet50 tile bag=64 bf16 --scratch (the headline step), eager", s2e, 64, "tiles/s")
+    m = fill(R.MILresnet50()); m.setmode("tile"); m.set_encoder_grads(True); m.train()
+    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, capturable=True, fused=FUSED)
+
+    def s2g_body(xb, yb):
+        optg.zero_grad(set_to_none=True)
+        loss = HF.cross_entropy(m(xb, freeze_bn=True), yb)
+        loss.backward()
+        optg.step()
+        return loss.detach()
+    g2 = GraphedStep(s2g_body, (x, y))
+    run("c2g the same step as one HIP graph (torch fused capturable Adam)", lambda: g2(x, y), 64, "tiles/s")
 if "c2f" in which:
     m = fill(R.MILresnet50()); m.setmode("tile"); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
