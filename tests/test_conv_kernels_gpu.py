@@ -55,7 +55,8 @@ def _relerr(a, b):
 # The register-staged twin (the production rule for operands >= 2 GiB) and the experimental streaming kernel are reachable at test
 # sizes only through cs_set_igemm_path, which exists in the A/B flavour of the library (`make AB=1`): the children started by
 # test_wave_specialised_weight_gradient_on_every_shape run this file with CELLSEG_LIB_FLAVOUR=ab and get all three paths.
-_PATHS = [(0, "lds_dma"), (1, "reg_staged"), (3, "lds_dma+stream")] if os.environ.get("CELLSEG_LIB_FLAVOUR") == "ab" else [(0, "lds_dma")]
+_PATHS = ([(0, "lds_dma"), (1, "reg_staged"), (3, "lds_dma+stream")]
+          if os.environ.get("CELLSEG_LIB_FLAVOUR") == "ab" and os.environ.get("CELLSEG_TEST_IGEMM_PATHS", "all") == "all" else [(0, "lds_dma")])
 
 
 @pytest.fixture(params=[p for p, _ in _PATHS], ids=[i for _, i in _PATHS])
@@ -330,10 +331,13 @@ def test_wave_specialised_weight_gradient_on_every_shape(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("1", "2"):
-        env = dict(os.environ, CELLSEG_WGRAD_SPEC=mode, CELLSEG_LIB_FLAVOUR="ab")
+        # (the first child also walks the three staging paths of the first-generation kernels; the grandchildren of the packed file's own
+        # forced-mode test and its bag-size sweep are left to the parent run)
+        env = dict(os.environ, CELLSEG_WGRAD_SPEC=mode, CELLSEG_LIB_FLAVOUR="ab", CELLSEG_TEST_IGEMM_PATHS="all" if mode == "1" else "dma")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_conv_kernels_gpu.py"),
                             os.path.join(root, "tests", "test_conv_packed_gpu.py"), "-m", "gpu", "-x", "-q",
-                            "-k", "not wave_specialised"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+                            "-k", "not wave_specialised and not wide_kernel_forced and not first_generation_over"],
+                           capture_output=True, text=True, timeout=1200, env=env, cwd=root)
         assert r.returncode == 0, (mode, (r.stdout + r.stderr)[-3000:])
 
 
