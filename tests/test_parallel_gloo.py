@@ -146,3 +146,31 @@ def test_shard_bags_never_splits_a_bag():
     shards = [shard_bags(10, r, 4) for r in range(4)]
     assert sorted(sum(shards, [])) == list(range(10))
     assert shards[0] == [0, 4, 8] and shards[3] == [3, 7]
+
+
+def test_bucket_layout_tapers_the_engine_part_and_keeps_the_rest_apart():
+    """GradReducer._build: the gradients the engine reports during backward (in the order it finishes them) get a tapered tail --
+    buckets of at most 1/2, 1/4, 1/8, 1/16 of `bucket_bytes` at the very end, where nothing is left to hide an all-reduce behind --
+    and parameters the engine never reports sit in buckets of their own behind them.  No process group involved."""
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in [4096] * 40 + [1000, 300, 64, 64]]      # 40 x 16 KiB, then small ones
+    rest = [torch.nn.Parameter(torch.zeros(n)) for n in (512, 8)]
+    red = GradReducer(params + rest, bucket_bytes=128 << 10)
+    for p in params:                                  # what the first attached step records
+        red._order_ids.add(id(p))
+        red._order.append(p)
+    red._build(red._order + rest, taper=True, n_engine=len(params))
+    sizes = [b.flat.numel() * 4 for b in red.buckets]
+    members = [[id(p) for p, _, _ in b.items] for b in red.buckets]
+    assert [i for m in members for i in m] == [id(p) for p in params + rest]          # order kept, everything placed once
+    rest_ids = {id(p) for p in rest}
+    n_rest = sum(1 for m in members if set(m) & rest_ids)
+    assert n_rest == red.n_rest_buckets == 1 and set(members[-1]) == rest_ids           # the rest: its own bucket(s), last
+    eng = sizes[:len(sizes) - n_rest]
+    assert max(eng) <= 128 << 10
+    # tapered tail: a bucket closes once it holds at least its cap (whole parameters: 16 KiB here), caps 1/16, 1/8, 1/4, 1/2 from the end
+    assert eng[-1] <= (128 << 10) // 4 and eng[-2] <= (128 << 10) // 4 and eng[-3] <= (128 << 10) // 2 and eng[-4] <= 128 << 10
+    assert eng[-2] < eng[-3] < eng[-4] <= eng[0] == 128 << 10                               # ... behind full-size buckets
+    # slices start on 256-byte boundaries and views alias the flat buffers
+    for b in red.buckets:
+        for (p, o, n), v in zip(b.items, b.views):
+            assert o % 64 == 0 and v.data_ptr() == b.flat.data_ptr() + 4 * o and v.shape == p.shape
