@@ -81,6 +81,7 @@ _SIGNATURES = {
     "cs_adam_chunk_elems": (c_int, []),
     "cs_adam_max_tensors": (c_int, []),
     "cs_adam_step": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
+    "cs_adam_step_dev": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P, c_double, c_double, c_double, c_double, c_double, _P]),
     "cs_sample_sum_workspace": (c_size_t, [c_int, c_int, c_int]),
     "cs_sample_sum": (c_int, [_P, _P, c_int, c_float, _P, _P, c_int, c_int, c_int, _P]),
     "cs_maxpool3x3s2_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -10,7 +10,7 @@ extern "C" void cs_set_error_(const char* msg) {
     strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
     g_err[sizeof(g_err) - 1] = '\0';
 }
-extern "C" int cs_abi_version(void) { return 5; }   // 3: packed-operand convolutions (conv_v2), packed layouts in CsStageDesc; 4: round-3 entry points (cs_adam_step, cs_sample_sum, ...); 5: cs_set_igemm_path left the production library (A/B flavour only), CS_BN_BWD_* flags
+extern "C" int cs_abi_version(void) { return 6; }   // 3: packed-operand convolutions (conv_v2), packed layouts in CsStageDesc; 4: round-3 entry points (cs_adam_step, cs_sample_sum, ...); 5: cs_set_igemm_path left the production library (A/B flavour only), CS_BN_BWD_* flags; 6: cs_adam_step_dev (device step counts: capturable)
 extern "C" const char* cs_last_error(void) { return g_err; }
 
 // name of the conv-family kernel instantiation the calling thread launched last (set by the launchers)

@@ -27,10 +27,18 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, flo
     p = p - step_size * (m / denom);
 }
 
+// `coef` (capturable form, cs_adam_step_dev): the per-tensor (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)) pairs adam_prep_kernel left in
+// device memory for this launch; NULL: the two by-value arguments.
 __global__ __launch_bounds__(256) void adam_multi_kernel(const CsAdamTensor* __restrict__ tensors, AdamGrads grads, const int2* __restrict__ chunks,
-                                                         int t0, float step_size, float inv_sqrt_bc2, float omb1, float beta2, float omb2, float eps, float wd) {
+                                                         int t0, float step_size, float inv_sqrt_bc2, float omb1, float beta2, float omb2, float eps, float wd,
+                                                         const float2* __restrict__ coef) {
     const int2 ch = chunks[blockIdx.x];                      // (tensor index, first element / kAdamChunk)
     const CsAdamTensor t = tensors[ch.x];
+    if (coef) {
+        const float2 c2 = coef[ch.x];
+        step_size = c2.x;
+        inv_sqrt_bc2 = c2.y;
+    }
     const float* __restrict__ g = nullptr;
     {
         const int li = ch.x - t0;
@@ -73,6 +81,22 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const CsAdamTensor* __r
     }
 }
 
+// Capturable form: the step counts live in DEVICE memory (one fp32 scalar per tensor: torch.optim.Adam(capturable=True)'s state
+// layout), so a launch captured into a HIP graph advances them at every replay.  One thread per tensor: t = ++step, the bias
+// corrections in double (device pow), the learning rate from a device double when the caller keeps one (schedulers change it
+// between replays of a captured step).
+__global__ void adam_prep_kernel(float* const* __restrict__ steps, int t0, int n, const double* __restrict__ lr_dev, double lr, double beta1,
+                                 double beta2, float2* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* sp = steps[t0 + i];
+    const float t = *sp + 1.0f;
+    *sp = t;
+    const double l = lr_dev ? *lr_dev : lr;
+    const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+    coef[t0 + i] = make_float2((float)(l / bc1), (float)(1.0 / sqrt(bc2)));
+}
+
 }  // namespace
 
 extern "C" int cs_adam_chunk_elems(void) { return kAdamChunk; }
@@ -93,7 +117,31 @@ extern "C" int cs_adam_step(const CsAdamTensor* tensors_dev, const void* const* 
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tensors_dev, gr,
                        reinterpret_cast<const int2*>(chunks_dev), t0, step_size, inv_sqrt_bc2, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)weight_decay);
+                       (float)weight_decay, static_cast<const float2*>(nullptr));
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_adam_step_dev(const CsAdamTensor* tensors_dev, const void* const* grads_host, int t0, int n_tensors, const int* chunks_dev,
+                                int n_chunks, float* const* steps_dev, float* coef_dev, const double* lr_dev, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, void* stream) {
+    CS_CHECK_ARG(tensors_dev && grads_host && chunks_dev && steps_dev && coef_dev && t0 >= 0 && n_tensors >= 1 && n_tensors <= kAdamMaxTensors &&
+                     n_chunks >= 1,
+                 "adam_step_dev: 1..320 tensors per call, device tables (tensors, chunks, step pointers, coefficient scratch), a HOST array "
+                 "of gradient pointers");
+    CS_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "adam_step_dev: betas in [0, 1)");
+    AdamGrads gr{};
+    for (int i = 0; i < n_tensors; ++i) {
+        CS_CHECK_ARG(grads_host[i], "adam_step_dev: NULL gradient");
+        gr.g[i] = reinterpret_cast<const float*>(grads_host[i]);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_prep_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, st, steps_dev, t0, n_tensors, lr_dev, lr, beta1, beta2,
+                       reinterpret_cast<float2*>(coef_dev));
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, tensors_dev, gr, reinterpret_cast<const int2*>(chunks_dev), t0,
+                       0.0f, 0.0f, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                       reinterpret_cast<const float2*>(coef_dev));
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

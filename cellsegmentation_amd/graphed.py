@@ -7,8 +7,14 @@ current stream with caller-owned buffers and no host synchronisation, so a whole
 3.4 ms per step for that configuration.
 
 Constraints (torch's graph-capture rules): fixed input shapes (use the eager step for a ragged last batch), no `.item()` /
-`.cpu()` inside the step, an optimizer that supports capture (`torch.optim.Adam(..., capturable=True)`, SGD).  Parameters, BN
-running statistics and optimizer state are updated in place by the replay exactly as by the eager step.
+`.cpu()` inside the step, an optimizer that supports capture (`cellsegmentation_amd.optim.Adam(..., capturable=True)` -- the
+one-launch HIP Adam with its step counts on the device --, `torch.optim.Adam(..., capturable=True)`, SGD).  Parameters, BN
+running statistics and optimizer state are updated in place by the replay exactly as by the eager step.  Host code of the step
+does not run at a replay: a learning-rate scheduler is stepped by the caller after the call, and what it changed reaches the
+captured launches through a `pre_replay` hook (`optimizer.sync_hyper` of the HIP Adam).
+
+Round 5: the ResNet-50 tile step of train/train.py:29-42 (`--scratch`) is captured too (bench.py's headline; bit-for-bit equality
+with eager steps in tests/test_graphed_gpu.py): 6.0 ms of host work per step leave the critical path.
 """
 import torch
 
@@ -23,9 +29,11 @@ class GraphedStep:
     they do update the model), then captures one more into the graph without executing it.  Each call copies the new batch into
     the captured input buffers and replays; the returned tensors are the captured outputs (overwritten by the next call)."""
 
-    def __init__(self, step_fn, example_inputs, warmup=3):
+    def __init__(self, step_fn, example_inputs, warmup=3, pre_replay=()):
+        """pre_replay: callables run (eagerly, on the host) before the capture and before every replay -- e.g. `optimizer.sync_hyper`."""
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs a GPU")
+        self.pre_replay = tuple(pre_replay)
         self.static_inputs = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -34,6 +42,8 @@ class GraphedStep:
                 step_fn(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        for hook in self.pre_replay:
+            hook()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = step_fn(*self.static_inputs)
@@ -46,6 +56,8 @@ class GraphedStep:
                 raise ValueError("GraphedStep: input shape/dtype differs from the captured one; run the eager step for this batch")
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        for hook in self.pre_replay:
+            hook()
         self.graph.replay()
         # the replay updated parameters / BN statistics without running host code: cached staged weights are stale now
         engine.invalidate_staged()

@@ -62,6 +62,7 @@ class GradReducer:
         self._overlap_ok = True    # this step: gradients may be reduced from inside backward
         self._slot = {}            # id(param) -> (bucket, offset, numel)
         self.launches_in_backward = 0     # buckets sent before reduce() in the last step (diagnostics / tests)
+        self.unadopted_after_early_launch = 0      # gradients of the last step that had to be all-reduced on their own (see reduce())
         self.n_rest_buckets = 0           # buckets holding parameters the engine never reports (they can only go in reduce())
         self._timed = []
         self._build(list(reversed(self.params)))       # reverse order ~ the order gradients become ready
@@ -213,30 +214,54 @@ class GradReducer:
         """All-reduce(SUM)/world of every .grad, in place (finishes what backward has not already sent)."""
         if not self._active:
             return
-        sent_early = sum(1 for b in self.buckets if b.launched)
+        early = [b for b in self.buckets if b.launched]
+        sent_early = len(early)
+        inv = 1.0 / self.world
+        # Gradients delivered from inside backward are expected to have been ADOPTED by autograd as an alias of their bucket slice.
+        # AccumulateGrad does not always adopt: it clones when somebody else still references the tensor, and it SUMS when the
+        # parameter also received a gradient from plain autograd in the same backward (or under create_graph).  Then `.grad`
+        # holds the rank-local total and the slice only what the engine wrote.  For a bucket that is still here the pack below
+        # takes the total from `.grad`; for a bucket that already left, the parameter's `.grad` is all-reduced on its own (same
+        # program on every rank: the same parameters take this path everywhere, in the same order).
+        stragglers = []
+        for b in early:
+            for (p, _, _), view in zip(b.items, b.views):
+                g = p.grad
+                if g is not None and g.data_ptr() != self._slot[id(p)][2]:
+                    stragglers.append(g)
         for b in self.buckets:
             if b.launched:
                 continue
-            # pack what the engine did not write in place: gradients that came through plain autograd, or every gradient when
-            # this step could not overlap (accumulation into an existing .grad)
+            # pack what the engine did not write in place: gradients that came through plain autograd, gradients autograd did not
+            # adopt, or every gradient when this step could not overlap (accumulation into an existing .grad)
             for (p, _, _), view in zip(b.items, b.views):
                 if p.grad is None:
                     view.zero_()
                 elif p.grad.data_ptr() != view.data_ptr():
                     view.copy_(p.grad)
             self._launch(b)
+        if stragglers:
+            if stragglers[0].is_cuda:
+                self._stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._stream):
+                    for g in stragglers:
+                        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                        g.mul_(inv)
+            else:
+                for g in stragglers:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                    g.mul_(inv)
+        self.unadopted_after_early_launch = len(stragglers)
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
-        inplace = self._delivered if self._overlap_ok else ()          # gradients autograd adopted as an alias of their bucket slice
+        done = {id(g) for g in stragglers}
         for b in self.buckets:
             for (p, _, _), view in zip(b.items, b.views):
-                if id(p) in inplace:
-                    continue
                 g = p.grad
                 if g is None:
                     p.grad = view.clone()
-                elif g is not view and g.data_ptr() != view.data_ptr():
-                    g.copy_(view)
+                elif g.data_ptr() != self._slot[id(p)][2] and id(g) not in done:
+                    g.copy_(view)              # (skipped only where .grad IS the slice: nothing to copy)
         if self._attached and not self._layout_final and self._order:
             # first attached step done: lay the buckets out in the order the engine finishes gradients (everything the engine
             # never reported goes last, it is only available after backward anyway).  Old slices that .grad may still alias

@@ -138,8 +138,10 @@ def train_alternative(loader, epoch, total_epochs, model, device, crit_cls, crit
     """Alternating tile / image training for one epoch (train/train.py:210-300; no driver of the reference calls it).  Per batch
     `(data, labels)` with data = (images, tiles) and labels = (image class, image count, tile label): a TILE step (setmode("tile"),
     plain forward -- the reference passes no freeze_bn here --, loss gamma * crit_cls) and an IMAGE step (setmode("image"),
-    alpha * crit_cls + beta * crit_reg) on ONE optimizer, zero_grad in between: the encoder is updated by both, each head by its own
-    step (cellsegmentation_amd.optim.Adam keeps a step count per parameter, as torch.optim.Adam does).  `threshold` and `delta`
+    alpha * crit_cls + beta * crit_reg) on ONE optimizer, zero_grad in between.  setmode("tile") freezes the encoder, as in the
+    reference (resnet.py:308-333), so the tile step updates the tile head only and the image step the encoder + the image heads: in
+    this loop every trained parameter ends an iteration at the same step count (cellsegmentation_amd.optim.Adam keeps a step count
+    per parameter, as torch.optim.Adam does, for schedules where parameters do skip steps).  `threshold` and `delta`
     are unused by the reference too (its segmentation part is commented out).  Returns
     (tile_loss, image_cls_loss, image_reg_loss, image_seg_loss = 0.0, image_loss)."""
     tile_num = 0

@@ -233,6 +233,17 @@ int cs_adam_chunk_elems(void);
 int cs_adam_max_tensors(void);
 int cs_adam_step(const CsAdamTensor* tensors_dev, const void* const* grads_host, int t0, int n_tensors, const int* chunks_dev,
                  int n_chunks, double lr, double beta1, double beta2, double eps, double weight_decay, double step, void* stream);
+/* The same update with the step counts in DEVICE memory (torch.optim.Adam(capturable=True)'s state layout: one fp32 scalar per
+ * tensor), so that a training step captured into a HIP graph (cellsegmentation_amd.graphed.GraphedStep over the loop body
+ * train/train.py:29-42) advances them at every replay.  Two launches: one thread per tensor does t = ++*steps_dev[row] and leaves
+ * (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)) -- formed in double -- in coef_dev[row]; the update kernel reads them from there.
+ *   steps_dev : DEVICE array, one `float*` per ROW of tensors_dev (rows [t0, t0 + n_tensors) are used)
+ *   coef_dev  : DEVICE scratch of 2 floats per row of tensors_dev (caller-owned, overwritten)
+ *   lr_dev    : DEVICE double holding the learning rate, or NULL to use `lr` (a captured launch keeps its by-value arguments
+ *               for ever: schedulers that change lr between replays write it here) */
+int cs_adam_step_dev(const CsAdamTensor* tensors_dev, const void* const* grads_host, int t0, int n_tensors, const int* chunks_dev,
+                     int n_chunks, float* const* steps_dev, float* coef_dev, const double* lr_dev, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, void* stream);
 
 /* Per-sample, per-channel sums of an NHWC tensor [N][HW][C]: out[n][c] = scale * sum_p a[n][p][c] (* b[n][p][c] when b != NULL),
  * fp32 [N][C], overwritten.  The two reductions of a squeeze-excitation block (torchvision SqueezeExcitation as used by

@@ -120,3 +120,97 @@ def test_adam_step_refuses_stream_capture(dev):
             with torch.cuda.graph(graph, stream=s):
                 a.step()
     torch.cuda.synchronize()
+
+
+def test_adam_capturable_matches_torch_eagerly(dev):
+    """capturable=True: step counts on the device (cs_adam_step_dev), run eagerly -- against torch.optim.Adam over alternating
+    parameter sets (per-parameter step counts in ONE launch), a learning-rate change, and state interchange both ways."""
+    import copy
+    shapes = [(64, 3, 7, 7), (64,), (256, 64, 1, 1), (2, 2048), (17,), (100003,)] + [(33, 5)] * 330          # > 320 tensors: two launches
+    ours, ref = _params(dev, shapes, 1), _params(dev, shapes, 1)
+    a = O.Adam(ours, lr=5e-4, weight_decay=1e-4, capturable=True)
+    b = torch.optim.Adam(ref, lr=5e-4, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(7)
+    for step in range(6):
+        for i, (p, q) in enumerate(zip(ours, ref)):
+            if i % 3 == 1 and step % 2 == 1:                  # a third of the tensors skips every other step
+                p.grad = q.grad = None
+                continue
+            gr = torch.randn(p.shape, generator=g).to(dev)
+            p.grad, q.grad = gr, gr.clone()
+        if step == 3:
+            a.param_groups[0]["lr"] = b.param_groups[0]["lr"] = 1e-3
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ours, ref):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
+        st = a.state[p]["step"]
+        assert st.is_cuda and st.dtype == torch.float32 and float(st) == float(b.state[q]["step"])
+    # ours -> torch (capturable) and torch -> ours, one more identical step each way
+    b2 = torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-4, capturable=True)
+    b2.load_state_dict(copy.deepcopy(a.state_dict()))
+    a2 = O.Adam(ours, lr=1e-3, weight_decay=1e-4, capturable=True)
+    a2.load_state_dict(copy.deepcopy(b.state_dict()))           # host step counts -> device fp32 scalars (Optimizer.load_state_dict)
+    for p, q in zip(ours, ref):
+        gr = torch.ones_like(p)
+        p.grad, q.grad = gr, gr.clone()
+    a2.step()
+    b2.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ours, ref):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
+        assert float(a2.state[p]["step"]) == float(b2.state[q]["step"])
+
+
+def test_adam_capturable_replays_as_successive_steps(dev):
+    """step() of the capturable form captured into a HIP graph: every replay is the NEXT Adam step (bias corrections from the
+    device step counts), a learning-rate change reaches the captured launches through sync_hyper(), and the result equals the same
+    optimizer stepped eagerly BIT FOR BIT."""
+    shapes = [(128, 64, 3, 3), (128,), (2, 2048), (4099,)]
+    ours, eag, ref = _params(dev, shapes, 5), _params(dev, shapes, 5), _params(dev, shapes, 5)
+    a = O.Adam(ours, lr=5e-4, weight_decay=1e-4, capturable=True)
+    e = O.Adam(eag, lr=5e-4, weight_decay=1e-4, capturable=True)
+    b = torch.optim.Adam(ref, lr=5e-4, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(9)
+    static = [torch.zeros_like(p) for p in ours]
+    for p, s in zip(ours, static):
+        p.grad = s
+
+    def feed():
+        for s, q, r in zip(static, eag, ref):
+            gr = torch.randn(s.shape, generator=gen).to(dev)
+            s.copy_(gr)
+            q.grad, r.grad = gr.clone(), gr.clone()
+
+    feed()
+    a.step(); e.step(); b.step()              # eager first step: state and device tables exist
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            a.step()                           # captured, not executed
+    torch.cuda.current_stream().wait_stream(side)
+    for k in range(5):
+        if k == 3:
+            for o in (a, e, b):
+                o.param_groups[0]["lr"] = 2e-3
+            a.sync_hyper()
+        feed()
+        graph.replay()
+        e.step(); b.step()
+    torch.cuda.synchronize()
+    for p, q, r in zip(ours, eag, ref):
+        assert torch.equal(p, q)                                        # graph replay == eager, same kernels
+        assert float((p - r).abs().max()) <= 2e-6 * max(1.0, float(r.abs().max()))
+        assert float(a.state[p]["step"]) == 6.0 == float(b.state[r]["step"])
+    # a changed lr without sync_hyper() is refused inside a capture (the fill would be baked into the graph)
+    a.param_groups[0]["lr"] = 3e-3
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="sync_hyper"):
+            with torch.cuda.graph(g2, stream=side):
+                a.step()
+    torch.cuda.synchronize()

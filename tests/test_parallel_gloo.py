@@ -142,6 +142,65 @@ def test_grad_reducer_overlaps_from_inside_backward_world2_gloo():
         assert refused
 
 
+def _unadopted_worker(rank, world, port, q):
+    """autograd's AccumulateGrad does NOT always adopt the tensor deliver() returns as `.grad` -- a parameter that
+    also receives a gradient from plain autograd in the same backward gets the SUM in a fresh tensor, an extra reference makes it a
+    clone.  Emulated here for two parameters: one whose bucket leaves from inside backward, one whose bucket is still there in
+    reduce().  `.grad` must come out as the average of the rank-local TOTALS either way."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 300, 5, 129, 64, 2)]
+    red = GradReducer(params, bucket_bytes=1024).attach()
+    summed, cloned = {1, 4}, {3}             # indices: engine gradient + an autograd contribution / adopted as a clone
+
+    def local(i, r, step):
+        return float((r + 1) * (i + 1) + step)
+
+    def extra(i, r):
+        return float(10 * (r + 1) + i)
+
+    ok, stragglers = True, []
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        for i, p in reversed(list(enumerate(params))):
+            v = red.view_for(p)
+            v.copy_(torch.full_like(p, local(i, rank, step)))
+            out = red.deliver(p, v)
+            if i in summed:
+                p.grad = out + extra(i, rank)          # a new tensor holding the rank-local total
+            elif i in cloned:
+                p.grad = out.clone()
+            else:
+                p.grad = out
+        red.reduce()
+        stragglers.append(red.unadopted_after_early_launch)
+        for i, p in enumerate(params):
+            want = sum(local(i, r, step) + (extra(i, r) if i in summed else 0.0) for r in range(world)) / world
+            ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+    red.detach()
+    q.put((rank, bool(ok), stragglers, len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_survives_gradients_autograd_did_not_adopt_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unadopted_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ok, stragglers, nb in res:
+        assert ok
+        assert nb > 1
+        assert stragglers[0] == 0            # first step: nothing leaves early, everything is packed from .grad in reduce()
+        assert stragglers[1] == stragglers[2] == 3      # later steps: every bucket leaves during backward -> three own all-reduces
+
+
 def test_shard_bags_never_splits_a_bag():
     shards = [shard_bags(10, r, 4) for r in range(4)]
     assert sorted(sum(shards, [])) == list(range(10))
