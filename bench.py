@@ -99,6 +99,14 @@ def conv_bytes(kind, g, es):
     x = g["N"] * g["H"] * g["W"] * g["C"] * es
     y = g["N"] * g["P"] * g["Q"] * g["K"] * es
     w = g["K"] * g["R"] * g["S"] * g["C"]
+    if g["R"] == 1 and g["S"] == 1 and g["stride"] > 1:
+        # a strided 1x1 convolution touches one pixel in stride^2 (forward and weight gradient read x at the sampled pixels only;
+        # the compact data gradient's destination is already counted by `extra` = -0.75): VERDICT r4 item 8
+        xs = g["N"] * g["P"] * g["Q"] * g["C"] * es
+        if kind == "fwd":
+            return xs + y + w * es + g["extra"] * y
+        if kind == "wgrad":
+            return (xs + y + w * 4) * g.get("batch", 1)
     if kind == "fwd":
         return x + y + w * es + g["extra"] * y
     if kind == "dgrad":
@@ -382,11 +390,54 @@ def secondary_configs(timeout_s=240):
     return out
 
 
-def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
+def _rccl_debug_env():
+    """Ask RCCL for its INIT / TUNING log lines in a per-process file (before the communicator exists), unless the caller already
+    configured NCCL_DEBUG.  Returns the file of THIS process or None."""
+    if "NCCL_DEBUG" in os.environ:
+        return os.environ.get("NCCL_DEBUG_FILE")
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"cellseg_rccl_{os.getpid()}.log")
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING,GRAPH"
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def _parse_rccl_log(path, max_lines=12):
+    """nranks, channel count and the (algorithm, protocol) lines RCCL printed for its collectives: whatever of it this RCCL build
+    writes (the format is RCCL's, so this only pattern-matches and keeps a short excerpt)."""
+    import re
+    out = {"log": path}
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except (OSError, TypeError):
+        return out
+    algos, excerpt = [], []
+    for ln in lines:
+        m = re.search(r"nranks\s+(\d+)", ln)
+        if m:
+            out["nranks_in_log"] = int(m.group(1))
+        m = re.search(r"(\d+)\s+coll channels", ln)
+        if m:
+            out["coll_channels"] = int(m.group(1))
+        if re.search(r"algo", ln, re.I) and re.search(r"proto", ln, re.I):
+            key = re.sub(r"^.*NCCL INFO\s*", "", ln)
+            key = re.sub(r"\b(time|opCount|count|datatype|stream|comm)\b[ =:]*\S+", "", key).strip()
+            if key not in algos:
+                algos.append(key)
+        if any(t in ln for t in ("Connected all", "Init COMPLETE", "Using network", "xgmi", "XGMI", "P2P")) and len(excerpt) < max_lines:
+            excerpt.append(re.sub(r"^.*NCCL INFO\s*", "", ln)[:160])
+    out["algo_proto"] = algos[:max_lines]
+    out["excerpt"] = excerpt
+    return out
+
+
+def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3, use_graph=False):
     """N = 1 only, outside the timed region: the same step with the gradient exchange switched ON over a one-rank RCCL
     communicator (`GradReducer(force_collectives=True)`: 32 MB flat buckets all-reduced from inside the HIP backward on a side
     stream).  A world of one moves no bytes over xGMI, so what this prices is everything else the N > 1 path adds to a step: the
-    RCCL kernel launches, the side-stream hand-offs and the 1/world scaling pass.  Never `value`."""
+    RCCL kernel launches, the side-stream hand-offs and the 1/world scaling pass.  With `use_graph` the step -- collectives
+    included -- is additionally captured into one HIP graph and replayed (what `bench.py --gpus N --graph` runs).  Never `value`."""
     import socket
     import torch.distributed as dist
     own_pg = not dist.is_initialized()
@@ -397,32 +448,53 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(port))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        rccl_log = _rccl_debug_env()
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    else:
+        rccl_log = os.environ.get("NCCL_DEBUG_FILE")
     red = GradReducer(params, force_collectives=True).attach()
     red.broadcast_parameters(model)
 
-    def step():
+    def step_fn(xb, lb):
         opt.zero_grad(set_to_none=True)
-        loss = HF.cross_entropy(model(x, freeze_bn=True), labels, 1.0)
+        loss = HF.cross_entropy(model(xb, freeze_bn=True), lb, 1.0)
         loss.backward()
         red.reduce()
         opt.step()
+        return loss.detach()
 
-    try:
-        for _ in range(warmup):
-            step()
+    def run(one, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        t_host = (time.perf_counter() - t0) / steps          # host time to ENQUEUE a step (the GPU may still be running)
+        for _ in range(n):
+            one()
+        t_host = (time.perf_counter() - t0) / n              # host time to ENQUEUE a step (the GPU may still be running)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        return (time.perf_counter() - t0) / n, t_host
+
+    graph_out = None
+    try:
+        for _ in range(warmup):
+            step_fn(x, labels)
+        dt, t_host = run(lambda: step_fn(x, labels), steps)
         early = red.launches_in_backward
         aliased = sum(1 for p in params if p.grad is not None and red._slot[id(p)][2] == p.grad.data_ptr())
         red.time_collectives = True
-        step()
+        step_fn(x, labels)
         times = red.collective_times()
+        exposed = red.exposed_ms()
+        red.time_collectives = False
+        if use_graph:
+            try:
+                from cellsegmentation_amd.graphed import GraphedStep
+                g = GraphedStep(step_fn, (x, labels), warmup=1, pre_replay=(opt.sync_hyper,))
+                g(x, labels)
+                gdt, gh = run(lambda: g(x, labels), steps)
+                graph_out = {"ms_per_step_with_collectives": round(gdt * 1e3, 3), "tiles_per_s": round(BAG / gdt, 1),
+                             "host_enqueue_ms_per_step": round(gh * 1e3, 3), "buckets_sent_inside_backward": red.launches_in_backward}
+                del g
+            except Exception as e:  # noqa: BLE001 -- the capture of RCCL collectives is the thing under test here
+                graph_out = {"error": f"{type(e).__name__}: {e}"[:300]}
     finally:
         red.detach()
         if own_pg:
@@ -430,9 +502,12 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3):
     return {"ms_per_step_with_collectives": round(dt * 1e3, 3), "tiles_per_s": round(BAG / dt, 1), "steps": steps,
             "host_enqueue_ms_per_step": round(t_host * 1e3, 3), "gradients_aliasing_their_bucket": f"{aliased}/{len(params)}",
             "buckets": len(red.buckets), "buckets_sent_inside_backward": early,
-            "allreduce_ms_per_step": round(sum(t for _, t in times), 4),
+            "allreduce_ms_per_step": round(sum(t for _, t in times), 4), "exposed_ms": round(exposed, 4),
             "per_bucket": [{"mbytes": round(n / 1e6, 2), "ms": round(t, 4)} for n, t in times],
-            "note": "one-rank RCCL communicator (backend nccl): all-reduce + 1/world scale per bucket, event-timed on the side stream"}
+            "rccl_log": _parse_rccl_log(rccl_log),
+            "as_one_hip_graph": graph_out,
+            "note": "one-rank RCCL communicator (backend nccl): all-reduce + 1/world scale per bucket, event-timed on the side stream; "
+                    "top-level figures = eager step, as_one_hip_graph = the same step with its collectives captured and replayed"}
 
 
 def main():
@@ -449,6 +524,8 @@ def main():
     ap.add_argument("--no-rccl-side", action="store_true", help="skip the one-rank RCCL side run (N=1)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs (N=1)")
     ap.add_argument("--per-layer", action="store_true", help="also print a per-geometry launch table to stderr")
+    ap.add_argument("--eager", action="store_true", help="enqueue every step from Python (no HIP graph); the default at N > 1")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph at N > 1 too (RCCL collectives captured)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -473,9 +550,11 @@ def main():
     dev_index = local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rccl_log = None
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
+            rccl_log = _rccl_debug_env()
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
@@ -485,8 +564,12 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     # the Adam update the reference constructs (train_tile.py:282) as ONE HIP launch (cellsegmentation_amd.optim.Adam, csrc/optim.hip;
     # tests/test_optim_gpu.py holds it to torch.optim.Adam step by step); --torch-adam: torch's own fused implementation (5 launches)
+    # The step is replayed as ONE HIP graph (graphed.GraphedStep; tests/test_graphed_gpu.py: bit-for-bit the eager step) at N = 1:
+    # ~220 launches cost 6 ms of Python + ctypes per step against ~7 ms of GPU work, so the eager step is within a few percent of
+    # host-bound.  At N > 1 the eager path is the default (the captured-RCCL path has never run on more than one rank; --graph).
+    use_graph = not args.eager and not args.torch_adam and (world == 1 or args.graph)
     opt = (torch.optim.Adam(params, lr=5e-4, weight_decay=1e-4, fused=True) if args.torch_adam
-           else Adam(params, lr=5e-4, weight_decay=1e-4))
+           else Adam(params, lr=5e-4, weight_decay=1e-4, capturable=use_graph))
     reducer = GradReducer(params).attach() if world > 1 else None       # buckets leave from inside the HIP backward
     if reducer is not None:
         reducer.broadcast_parameters(model)
@@ -496,18 +579,30 @@ def main():
     labels = torch.tensor([(i * 7 + 1) % 2 for i in range(BAG)], device=dev)
     loss_acc = torch.zeros((), device=dev)
 
-    def step():
+    def step_fn(xb, lb):
         opt.zero_grad(set_to_none=True)
-        out = model(x, freeze_bn=True)
-        loss = HF.cross_entropy(out, labels, 1.0)
+        out = model(xb, freeze_bn=True)
+        loss = HF.cross_entropy(out, lb, 1.0)
         loss.backward()
         if reducer is not None:
             reducer.reduce()
         opt.step()
         loss_acc.add_(loss.detach())
+        return loss.detach()
 
-    for _ in range(args.warmup):
-        step()
+    def step():
+        step_fn(x, labels)
+
+    gstep = None
+    if use_graph:
+        from cellsegmentation_amd.graphed import GraphedStep
+        # W warm-up steps in all: W - 1 eager ones inside GraphedStep (the capture itself executes nothing), then one replay
+        gstep = GraphedStep(step_fn, (x, labels), warmup=max(1, args.warmup - 1), pre_replay=(opt.sync_hyper,))
+        if args.warmup >= 2:
+            gstep(x, labels)
+    else:
+        for _ in range(args.warmup):
+            step()
 
     def barrier():
         if world > 1:
@@ -521,16 +616,35 @@ def main():
     # per-launch HIP events (two per conv-family launch, ~380 per step) cost ~1 ms of host time per step: they bracket the
     # launches of every `--event-every`-th timed step only, so the roofline is still measured live inside the timed region
     # while `value` is not taxed by its own instrumentation
+    # With the graph, the event-bracketed steps are the EAGER ones (a replay has no host-visible launches to bracket) and every other
+    # step is a replay (the batch is copied into the captured input buffer first, as a training loop would): the two kinds of step
+    # are bit-identical, so the K timed steps are K consecutive optimizer steps of one trajectory.
     timed_steps = 0
+    host_by_kind = {"graph": [0.0, 0], "eager": [0.0, 0]}
     if timer is not None:
         with timer:
             for i in range(args.steps):
                 timer.enabled = (i % args.event_every) == 0
                 timed_steps += int(timer.enabled)
-                step()
+                h0 = time.perf_counter()
+                if gstep is not None and not timer.enabled:
+                    gstep(x, labels)
+                    kind = "graph"
+                else:
+                    step()
+                    kind = "eager"
+                host_by_kind[kind][0] += time.perf_counter() - h0
+                host_by_kind[kind][1] += 1
     else:
         for _ in range(args.steps):
-            step()
+            h0 = time.perf_counter()
+            if gstep is not None:
+                gstep(x, labels)
+            else:
+                step()
+            kind = "graph" if gstep is not None else "eager"
+            host_by_kind[kind][0] += time.perf_counter() - h0
+            host_by_kind[kind][1] += 1
     host_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic: host- or GPU-bound)
     torch.cuda.synchronize()
     barrier()
@@ -541,8 +655,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # N > 1: one more step (outside the timed region, on every rank -- it is a collective) with each bucket's all-reduce and the
+    # compute stream's final wait bracketed by events, so that the first multi-GPU line explains itself
+    rccl_info = None
+    if reducer is not None:
+        reducer.time_collectives = True
+        step()
+        times = reducer.collective_times()
+        exposed = reducer.exposed_ms()
+        reducer.time_collectives = False
+        rccl_info = {"nranks": world, "backend": args.backend, "buckets": len(reducer.buckets),
+                     "buckets_sent_inside_backward": reducer.launches_in_backward,
+                     "allreduce_ms_per_step": round(sum(t for _, t in times), 4), "exposed_ms": round(exposed, 4),
+                     "per_bucket": [{"mbytes": round(n / 1e6, 2), "ms": round(t, 4)} for n, t in times],
+                     "log": _parse_rccl_log(rccl_log) if rccl_log else None}
+
     if rank == 0:
-        final_loss = float(loss_acc.item()) / max(1, args.steps + args.warmup)
+        final_loss = float(loss_acc.item()) / max(1, args.steps + args.warmup + (1 if reducer is not None else 0))
         roof = roofline_from(timer.results(), timed_steps, dtype) if timer is not None else None
         if roof is not None:
             roof["event_timed_steps"] = timed_steps
@@ -551,7 +680,7 @@ def main():
         rccl_side = None
         if world == 1 and not args.no_rccl_side:
             try:
-                rccl_side = rccl_world1_side(dev, model, params, opt, x, labels)
+                rccl_side = rccl_world1_side(dev, model, params, opt, x, labels, use_graph=use_graph)
             except Exception as e:  # noqa: BLE001 -- a side number must never take the headline line down
                 rccl_side = {"error": f"{type(e).__name__}: {e}"[:300]}
         secondary = None
@@ -575,6 +704,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+            "host_enqueue_detail": {k: {"steps": v[1], "ms_per_step": round(v[0] / v[1] * 1e3, 3)} for k, v in host_by_kind.items() if v[1]},
+            "step_mode": ("one HIP graph per step (graphed.GraphedStep: input copy + replay); every "
+                          f"{args.event_every}th timed step is enqueued eagerly and HIP-event-bracketed for `roofline`"
+                          if gstep is not None else "eager (every launch enqueued from Python)"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -586,6 +719,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "fp32_parity_mode": fp32_side,
+            "rccl": rccl_info,
             "rccl_world1": rccl_side,
             "secondary": secondary,
         }

@@ -65,6 +65,7 @@ class GradReducer:
         self.unadopted_after_early_launch = 0      # gradients of the last step that had to be all-reduced on their own (see reduce())
         self.n_rest_buckets = 0           # buckets holding parameters the engine never reports (they can only go in reduce())
         self._timed = []
+        self._exposed = []
         self._build(list(reversed(self.params)))       # reverse order ~ the order gradients become ready
 
     # ------------------------------------------------------------------ layout
@@ -209,6 +210,14 @@ class GradReducer:
         self._timed = []
         return out
 
+    def exposed_ms(self):
+        """Milliseconds the compute stream waited for the side stream in the reduce() calls since the last call (with
+        time_collectives on): the exchange time that backward did not cover.  Synchronises; diagnostics only."""
+        torch.cuda.synchronize()
+        out = sum(a.elapsed_time(b) for a, b in self._exposed)
+        self._exposed = []
+        return out
+
     @torch.no_grad()
     def reduce(self):
         """All-reduce(SUM)/world of every .grad, in place (finishes what backward has not already sent)."""
@@ -253,7 +262,16 @@ class GradReducer:
                     g.mul_(inv)
         self.unadopted_after_early_launch = len(stragglers)
         if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
+            cur = torch.cuda.current_stream()
+            if self.time_collectives:
+                # how long the compute stream sits in this wait = the part of the exchange backward did not hide
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(cur)
+                cur.wait_stream(self._stream)
+                eb.record(cur)
+                self._exposed.append((ea, eb))
+            else:
+                cur.wait_stream(self._stream)
         done = {id(g) for g in stragglers}
         for b in self.buckets:
             for (p, _, _), view in zip(b.items, b.views):

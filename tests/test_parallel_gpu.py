@@ -96,3 +96,84 @@ def test_engine_backward_feeds_the_reducer_two_ranks_one_gpu(dev):
         assert nb >= 3
         assert early[0] == 0                      # the first step records the order
         assert early[1] >= nb - 1 and early[2] >= nb - 1     # then all but (at most) the head's bucket leave inside backward
+
+
+def _ddp_worker(rank, world, port, q):
+    try:
+        _ddp_worker_body(rank, world, port, q)
+    except BaseException:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+def _ddp_worker_body(rank, world, port, q):
+    """The reference's own `--distributed` stub (train_tile.py:227-235): `nn.parallel.DistributedDataParallel(model,
+    device_ids=[local_rank], output_device=local_rank)` around the model -- here around the HIP model, whose whole trunk is ONE
+    autograd.Function: DDP's per-parameter hooks must still fire for every trainable parameter and leave the rank average in
+    `.grad`.  gloo instead of nccl only because RCCL refuses two ranks on one card."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cellsegmentation_amd import synth
+    from cellsegmentation_amd.model import resnet as R
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    m = R.MILresnet18()
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    m = m.to(dev).set_compute_dtype(torch.float32)
+    m.setmode("tile")
+    m.set_encoder_grads(True)
+    # the reference never toggles upconv5-8 (resnet.py:226-232): they stay trainable but unused in tile mode, which DDP (without
+    # find_unused_parameters, as in the reference's call) refuses from the second iteration on -- freeze what the mode does not use
+    for name, p in m.named_parameters():
+        if name.startswith(("upconv", "seg_out")):
+            p.requires_grad_(False)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.train()
+    params = [p for p in m.parameters() if p.requires_grad]
+    xs = [synth.normalise(synth.ihc_tiles(8, 32, 700 + r)).to(dev) for r in range(world)]
+    ys = [torch.tensor([(i + r) % 2 for i in range(8)], device=dev) for r in range(world)]
+
+    def local_grads(r):
+        for p in params:
+            p.grad = None
+        torch.nn.functional.cross_entropy(m(xs[r], freeze_bn=True), ys[r]).backward()
+        return [p.grad.clone() for p in params]
+
+    expect = [sum(gs) / world for gs in zip(*[local_grads(r) for r in range(world)])]      # single-process gradients, no DDP
+    for p in params:
+        p.grad = None
+    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], output_device=0)
+    worst = 0.0
+    for step in range(3):
+        ddp.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(ddp(xs[rank], freeze_bn=True), ys[rank]).backward()
+        for p, e in zip(params, expect):
+            assert p.grad is not None
+            worst = max(worst, float((p.grad - e).abs().max() / (e.abs().max() + 1e-12)))
+    torch.cuda.synchronize()
+    q.put((rank, worst, len(params)))
+    dist.destroy_process_group()
+
+
+def test_hip_model_inside_torch_ddp_two_ranks_one_gpu(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for r in res:
+        assert len(r) == 3, r[1]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _, worst, n in res:
+        assert n > 60                      # the whole ResNet-18 trunk + the tile head
+        assert worst < 1e-6, worst
