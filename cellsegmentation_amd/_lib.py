@@ -94,6 +94,8 @@ _SIGNATURES = {
     "cs_softmax_prob1": (c_int, [_P, _P, c_int, c_int, _P]),
     "cs_softmax_argmax": (c_int, [_P, _P, c_int, c_int, _P]),
     "cs_mse": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P]),
+    "cs_bn_accum_words": (c_size_t, [c_int]),
+    "cs_bn_accum_read": (c_int, [_P, c_int, _P, _P]),
     "cs_bn_stats": (c_int, [_P, c_int, c_longlong, c_int, _P, _P, _P]),
     "cs_bn_partial_workspace": (c_size_t, [c_longlong, c_int]),
     "cs_bn_finalize": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P, _P, c_int, _P]),

@@ -12,12 +12,12 @@
 
 namespace {
 
-// Two per-thread partial sums for 8 channels -> one fp64 atomic per channel per workgroup.
+// Two per-thread partial sums for 8 channels -> one exact (order-independent, cs_common.h: ex_add) contribution per channel per workgroup.
 // Threads are laid out tid = rr*width + (cg - cg0); rows rr < rpar hold valid partials.
 // partial != NULL: the workgroup's two sums go to partial[(2*blockIdx.x + {0,1}) * C + c] with plain stores instead (folded by
 // bn_partial_fold_kernel): ~1000 fp64 atomics per address serialise at the memory side and cost more than the streaming pass.
 __device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const float (&b)[8], int width, int rpar, int cg, bool live,
-                                                  double* out0, double* out1, double* partial = nullptr, int C = 0) {
+                                                  double* acc, int C, double* partial = nullptr) {
     __shared__ float fold[2][256][8];
     __syncthreads();
 #pragma unroll
@@ -39,7 +39,7 @@ __device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const flo
         for (int r = 0; r < rpar; ++r) t += (double)fold[a_][r * width + cgl][e];
         const int ch = (cg0 + cgl) * 8 + e;
         if (partial) partial[(2LL * blockIdx.x + a_) * C + ch] = t;
-        else atomicAdd((a_ ? out1 : out0) + ch, t);
+        else ex_add(acc, C, a_, ch, t);
     }
 }
 
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, 
                 for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
             }
         }
-        block_fold_atomic(s1, s2, width, rpar, cg, live, stats, stats + C, partial, C);
+        block_fold_atomic(s1, s2, width, rpar, cg, live, stats, C, partial);
     }
 }
 
@@ -100,7 +100,7 @@ __device__ __forceinline__ void bn_finalize_channel(const double* __restrict__ s
                                                     float* __restrict__ rstd_out) {
     float mean, rstd;
     double var;
-    bn_moments(stats[c], stats[C + c], M, eps, mean, rstd, var);
+    bn_moments(ex_read(stats, C, 0, c), ex_read(stats, C, 1, c), M, eps, mean, rstd, var);
     mean_out[c] = mean;
     rstd_out[c] = rstd;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 double var;
-                bn_moments(fin.stats[cg * 8 + e], fin.stats[C + cg * 8 + e], fin.M, fin.eps, mu[e], rs[e], var);
+                bn_moments(ex_read(fin.stats, C, 0, cg * 8 + e), ex_read(fin.stats, C, 1, cg * 8 + e), fin.M, fin.eps, mu[e], rs[e], var);
             }
         } else {
             load8p(mean + cg * 8, 0.f, mu);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 acc(g0, z0);
             }
         }
-        block_fold_atomic(s0, s1, width, rpar, cg, live, sums, sums + C, partial, C);
+        block_fold_atomic(s0, s1, width, rpar, cg, live, sums, C, partial);
     }
 }
 
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const float invM = 1.f / (float)M;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) dbeta[c] = (float)sums[c];
-            if (dgamma) dgamma[c] = (float)sums[C + c];
+            if (dbeta) dbeta[c] = (float)ex_read(sums, C, 0, c);
+            if (dgamma) dgamma[c] = (float)ex_read(sums, C, 1, c);
         }
     }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const bool frozen = (act & CS_BN_BWD_FROZEN) != 0;      // running statistics: mean / rstd do not depend on the batch
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            k0[e] = frozen ? 0.f : (float)sums[cg * 8 + e] * invM;
-            k1[e] = frozen ? 0.f : (float)sums[C + cg * 8 + e] * invM;
+            k0[e] = frozen ? 0.f : (float)ex_read(sums, C, 0, cg * 8 + e) * invM;
+            k1[e] = frozen ? 0.f : (float)ex_read(sums, C, 1, cg * 8 + e) * invM;
             gr[e] = gm[e] * rs[e];
         }
         auto finish = [&](float (&g)[8], const float (&zz)[8], const long long off) {
@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __re
     __shared__ double part[4][64];
     part[rl][threadIdx.x & 63] = a0 + a1;
     __syncthreads();
-    if (rl == 0 && j < cols && b0 < blocks) atomicAdd(out + j, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    if (rl == 0 && j < cols && b0 < blocks) {
+        const int C = cols >> 1;
+        ex_add(out, C, j >= C ? 1 : 0, j >= C ? j - C : j, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    }
 }
 
 // Up to this many workgroups a reduction adds its per-workgroup sums with fp64 atomics (<= 512 per address) instead of writing partial
@@ -399,6 +402,21 @@ inline int ew_rows_per_block(long long M, int C) {
     if (dtype == CS_F32) { CALL_F32; }                       \
     else if (dtype == CS_BF16) { CALL_BF16; }                \
     else { cs_set_error_(NAME ": bad dtype"); return CS_ERR_INVALID_ARG; }
+
+// One thread per (sum, channel): the exact accumulator's totals as doubles (tests, tools; the kernels read the limbs themselves).
+__global__ void bn_accum_read_kernel(const double* __restrict__ acc, int C, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * C) out[i] = ex_read(acc, C, i >= C ? 1 : 0, i >= C ? i - C : i);
+}
+
+extern "C" size_t cs_bn_accum_words(int C) { return C > 0 ? (size_t)ex_words(C) : 0; }
+
+extern "C" int cs_bn_accum_read(const double* accum, int C, double* out, void* stream) {
+    CS_CHECK_ARG(accum && out && C > 0, "bn_accum_read: bad arguments");
+    hipLaunchKernelGGL(bn_accum_read_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), accum, C, out);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
 
 extern "C" int cs_bn_partial_fold(const double* partial, int rows, int C, double* stats, void* stream) {
     CS_CHECK_ARG(partial && stats && rows > 0 && C > 0, "bn_partial_fold: bad arguments");

@@ -320,7 +320,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 float t = 0.f;
                 for (int r = cgl; r < 256; r += CG) t += red[r * 16 + j];
                 const int o_ = (j < 8 ? 0 : p.NOUT) + oc + (j & 7);
-                if (p.stat_atomic) atomicAdd(p.stat_atomic + o_, (double)t);
+                if (p.stat_atomic) ex_add(p.stat_atomic, p.NOUT, j < 8 ? 0 : 1, oc + (j & 7), (double)t);      // exact: any arrival order, same bits
                 else row[o_] = t;
             }
         }
@@ -897,9 +897,12 @@ __global__ __launch_bounds__(256) void igemm_stream_kernel(IgemmParams p, unsign
 }
 
 // Fold the per-workgroup partial rows: out[c] += sum_r slab[r][c] for c < ncols (row stride = stride).
-// Workgroup = 64 columns x 4 row lanes, gridDim.y row chunks -> <= gridDim.y atomics per address.
+// Workgroup = 64 columns x 4 row lanes, gridDim.y row chunks.  Every result repeats bit for bit (round 5): `stats` is an exact,
+// order-independent accumulator (ex_add); a float `colsum` target is added to by ONE workgroup per column when the grid has one row
+// chunk, and with several chunks each writes its sum into the dead second half of partial row blockIdx.y (`chunk_dst`: the sum-of-
+// squares columns, which a column-sum fold never reads) for colsum_chunk_fold_kernel to add in chunk order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int rows, int stride, int ncols,
-                                                          int nout, float* colsum, double* stats) {
+                                                          int nout, float* colsum, double* stats, float* chunk_dst) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     const int per = (rows + gridDim.y - 1) / gridDim.y;
@@ -924,9 +927,33 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     __syncthreads();
     if (rl == 0 && c < ncols) {
         const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (colsum && c < nout) atomicAdd(colsum + c, (float)t);
-        if (stats) atomicAdd(stats + c, t);
+        if (chunk_dst && c < nout) chunk_dst[(long long)blockIdx.y * stride + nout + c] = (float)t;
+        else if (colsum && c < nout) colsum[c] += (float)t;            // gridDim.y == 1: the only writer of this column
+        if (stats) ex_add(stats, nout, c >= nout ? 1 : 0, c >= nout ? c - nout : c, t);
     }
+}
+
+__global__ __launch_bounds__(256) void colsum_chunk_fold_kernel(const float* __restrict__ slab, int chunks, int stride, int nout,
+                                                                float* __restrict__ colsum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nout) return;
+    double t = 0.0;
+    for (int y = 0; y < chunks; ++y) t += (double)slab[(long long)y * stride + nout + c];
+    colsum[c] += (float)t;
+}
+
+// out[c] += sum over the partial rows, deterministic (see slab_reduce_kernel); `colsum` and `stats` are alternatives.
+int launch_slab_reduce(float* slab, int rows, int nout, float* colsum, double* stats, hipStream_t st) {
+    const int ncols = stats ? 2 * nout : nout;
+    int chunks = rows / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 32) chunks = 32;
+    const bool two_phase = colsum && !stats && chunks > 1;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((ncols + 63) / 64, chunks), dim3(256), 0, st, slab, rows, 2 * nout, ncols, nout, colsum, stats,
+                       two_phase ? slab : (float*)nullptr);
+    if (two_phase)
+        hipLaunchKernelGGL(colsum_chunk_fold_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, slab, chunks, 2 * nout, nout, colsum);
+    return 0;
 }
 
 // name of the kernel instantiation this thread launched last (cs_last_conv_variant): bench.py / tools/check_bench_vs_profile.py
@@ -1101,12 +1128,8 @@ int dispatch_igemm(const IgemmParams& p_in, float* colsum, double* stats, hipStr
         rows = 0;
         for (int i = 0; i < p.ncls; ++i) rows += (int)((p.cls[i].M + bm - 1) / bm);
     }
-    const int ncols = stats ? 2 * p.NOUT : p.NOUT;
-    int chunks = rows / 64;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 32) chunks = 32;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((ncols + 63) / 64, chunks), dim3(256), 0, st, p.slab, rows, 2 * p.NOUT, ncols, p.NOUT,
-                       colsum, stats);
+    CS_CHECK_ARG(!(colsum && stats), "igemm: column sums and statistics are alternatives");
+    launch_slab_reduce(p.slab, rows, p.NOUT, colsum, stats, st);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
@@ -1201,11 +1224,8 @@ extern "C" int cs_conv2d_dgrad_partial_rows(const CsConvGeom* g) {
 
 extern "C" int cs_fold_partial_rows(const float* partial, int rows, int n_out, float* out, void* stream) {
     CS_CHECK_ARG(partial && out && rows > 0 && n_out > 0, "fold_partial_rows: bad arguments");
-    int chunks = rows / 64;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 32) chunks = 32;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_out + 63) / 64, chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, rows,
-                       2 * n_out, n_out, n_out, out, (double*)nullptr);
+    // (the fold may use the dead sum-of-squares half of the first partial rows as scratch: `partial` is written)
+    launch_slab_reduce(const_cast<float*>(partial), rows, n_out, out, nullptr, reinterpret_cast<hipStream_t>(stream));
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -431,12 +431,21 @@ __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const T* __restrict__
             s1[e] += r; s2[e] += r * r;
         }
     }
-    if (first < total) {
+    // fixed-order fold of the threads that share a channel group (float LDS atomics added them in arrival order: not repeatable)
+    __shared__ float fold[256][16];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            atomicAdd(&lsum[cg * 8 + e], s1[e]);
-            atomicAdd(&lsum[C + cg * 8 + e], s2[e]);
-        }
+    for (int e = 0; e < 8; ++e) {
+        fold[threadIdx.x][e] = first < total ? s1[e] : 0.f;
+        fold[threadIdx.x][8 + e] = first < total ? s2[e] : 0.f;
+    }
+    __syncthreads();
+    const int t0 = (int)(((long long)blockIdx.x * 256) % CG);           // channel group of thread 0
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int a = i >= C ? 1 : 0, c = i - a * C;
+        const int cgc = c >> 3, e = c & 7;
+        float t = 0.f;
+        for (int th = (cgc - t0 + CG) % CG; th < 256; th += CG) t += fold[th][a * 8 + e];
+        lsum[i] = t;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += 256) partial[(long long)blockIdx.x * 2 * C + i] = (double)lsum[i];

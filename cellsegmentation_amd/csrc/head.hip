@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x < 3) {
         const double v = (double)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        atomicAdd(sums + n * 3 + threadIdx.x, v);
+        ex_add(sums, 3 * gridDim.y, 0, n * 3 + threadIdx.x, v);          // exact accumulator: any block order, same bits
     }
 }
 
@@ -304,7 +304,7 @@ __global__ void dice_loss_kernel(const double* __restrict__ sums, int N, float e
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float acc = 0.f;
     for (int n = 0; n < N; ++n) {
-        const float a = (float)sums[n * 3], b = (float)sums[n * 3 + 1], c = (float)sums[n * 3 + 2];
+        const float a = (float)ex_read(sums, 3 * N, 0, n * 3), b = (float)ex_read(sums, 3 * N, 0, n * 3 + 1), c = (float)ex_read(sums, 3 * N, 0, n * 3 + 2);
         acc += 1.f - (2.f * a + eps) / (b + c + eps);
     }
     loss[0] = mean ? acc / (float)N : acc;
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
                                                        const double* __restrict__ sums, long long HW, float eps, float scale,
                                                        float* __restrict__ dp) {
     const int n = blockIdx.y;
-    const float a = (float)sums[n * 3], b = (float)sums[n * 3 + 1], c = (float)sums[n * 3 + 2];
+    const int C3 = 3 * gridDim.y;
+    const float a = (float)ex_read(sums, C3, 0, n * 3), b = (float)ex_read(sums, C3, 0, n * 3 + 1), c = (float)ex_read(sums, C3, 0, n * 3 + 2);
     const float num = 2.f * a + eps, den = b + c + eps;
     const float k = -scale / (den * den);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
@@ -468,7 +469,7 @@ extern "C" int cs_dice_fwd(const float* p, const float* t, int N, long long HW, 
                            void* stream) {
     CS_CHECK_ARG(p && t && sums && loss && N > 0 && HW > 0, "dice_fwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * N, st) != hipSuccess) { cs_set_error_("dice_fwd: memset failed"); return CS_ERR_LAUNCH; }
+    if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)ex_words(3 * N), st) != hipSuccess) { cs_set_error_("dice_fwd: memset failed"); return CS_ERR_LAUNCH; }
     long long bx = (HW + 256 * 8 - 1) / (256 * 8);
     if (bx > 256) bx = 256;
     hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)bx, N), dim3(256), 0, st, p, t, HW, sums);

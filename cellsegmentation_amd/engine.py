@@ -336,16 +336,17 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
         K.begin_pass(t[plan.inputs[0]].device)
     bits = {}            # slot -> uint8 "output > 0" bit tensor (folded Conv+BN+ReLU outputs of a pass that will run backward)
     if bn_train:
-        need = sum(2 * K.pad_channels(u_.conv.out_channels) for u_ in plan.units
+        need = sum(K.accum_words(K.pad_channels(u_.conv.out_channels)) for u_ in plan.units
                    if u_.kind == "conv" and _bn_uses_batch_stats(u_.bn, bn_train))
         if need:
             stats_arena = torch.zeros((need,), dtype=torch.float64, device=t[plan.inputs[0]].device)
 
     def take_stats(C):
-        if stats_arena is None or stats_pos[0] + 2 * C > stats_arena.numel():
+        n = K.accum_words(C)
+        if stats_arena is None or stats_pos[0] + n > stats_arena.numel():
             return K.new_stats(C, t[plan.inputs[0]].device)
-        v = stats_arena[stats_pos[0]:stats_pos[0] + 2 * C].view(2, C)
-        stats_pos[0] += 2 * C
+        v = stats_arena[stats_pos[0]:stats_pos[0] + n]
+        stats_pos[0] += n
         return v
 
     for ui, u in enumerate(plan.units):

@@ -586,8 +586,14 @@ def colsum_partial(g):
 # per training pass (begin_pass) instead of one fill launch per accumulator (EfficientNet-B3: 104 fills of 4.8 us per step).
 # Every user consumes its accumulator inside the call that took it (stream order), so clearing the whole pool at the start of the
 # next pass is safe; without begin_pass (direct calls from tests / tools) the pool is used once and then falls back to torch.zeros.
-_STATS_POOL_ELEMS = 1 << 19
+_STATS_POOL_ELEMS = 1 << 21           # 8-byte words (16 MB): an exact accumulator takes 6 C + 1 of them (cs_bn_accum_words)
 _stats_pools = {}
+
+
+def accum_words(C):
+    """8-byte words of the exact per-channel accumulator of a C-channel BatchNorm reduction (cs_bn_accum_words: three integer limbs
+    per sum and channel + one flag word; order-independent adds, so batch statistics repeat bit for bit)."""
+    return 6 * C + 1
 
 
 def begin_pass(device):
@@ -600,12 +606,29 @@ def begin_pass(device):
 
 
 def new_stats(C, device):
+    """A zeroed exact accumulator for C channels (opaque words, dtype float64 for history; stats_values() reads the totals)."""
+    n = accum_words(C)
     pool = _stats_pools.get(device)
-    if pool is not None and pool[1] + 2 * C <= _STATS_POOL_ELEMS:
-        v = pool[0][pool[1]:pool[1] + 2 * C].view(2, C)
-        pool[1] += 2 * C
+    if pool is not None and pool[1] + n <= _STATS_POOL_ELEMS:
+        v = pool[0][pool[1]:pool[1] + n]
+        pool[1] += n
         return v
-    return torch.zeros((2, C), dtype=torch.float64, device=device)
+    return torch.zeros((n,), dtype=torch.float64, device=device)
+
+
+def stats_channels(stats):
+    n = stats.numel()
+    if n < 7 or (n - 1) % 6:
+        raise ValueError("not a BatchNorm accumulator (kernels.new_stats)")
+    return (n - 1) // 6
+
+
+def stats_values(stats):
+    """fp64 [2, C]: the two per-channel totals an exact accumulator holds (cs_bn_accum_read; tests and tools)."""
+    C = stats_channels(stats)
+    out = torch.empty((2, C), dtype=torch.float64, device=stats.device)
+    _lib.check(_lib.load().cs_bn_accum_read(_p(stats), C, _p(out), _stream()), "bn_accum_read")
+    return out
 
 
 def bn_stats(z, stats=None):
@@ -627,7 +650,7 @@ def _bn_ws(M, C, device):
 
 
 def bn_finalize(stats, M, eps, momentum, running_mean=None, running_var=None):
-    C = stats.shape[1]
+    C = stats_channels(stats)
     out = torch.empty((2, C), dtype=torch.float32, device=stats.device)
     _lib.check(_lib.load().cs_bn_finalize(_p(stats), M, eps, momentum, _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]), C,
                                           _stream()), "bn_finalize")
@@ -867,9 +890,10 @@ def mse(x, t, weighted=False, mean=True, want_grad=True):
 
 
 def dice_fwd(p, t, eps=1e-6, mean=True):
-    """p, t: [N, HW] fp32 contiguous. returns loss[1], sums[N,3] fp64"""
+    """p, t: [N, HW] fp32 contiguous. returns loss[1], sums: the per-sample (sum p t, sum p^2, sum t^2) as an exact accumulator of
+    accum_words(3 N) opaque words (cleared by the call, read by dice_bwd)"""
     N, HW = p.shape
-    sums = torch.empty((N, 3), dtype=torch.float64, device=p.device)
+    sums = torch.empty((accum_words(3 * N),), dtype=torch.float64, device=p.device)
     loss = torch.empty((1,), dtype=torch.float32, device=p.device)
     _lib.check(_lib.load().cs_dice_fwd(_p(p), _p(t), N, HW, eps, 1 if mean else 0, _p(sums), _p(loss), _stream()), "dice_fwd")
     return loss, sums

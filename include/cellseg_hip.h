@@ -65,11 +65,20 @@ int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const f
 
 /* ---- BatchNorm in train mode (batch statistics; model.train(), resnet.py:21,52,112,184,199 and the
  * BatchNorm1d of the image heads, resnet.py:134,138) over NHWC rows z[M][C] ----------------------
- * stats: fp64 [2][C] (sum, sum of squares), zeroed by the caller; also filled by cs_conv2d_fwd. */
+ * stats: the per-channel pair (sum, sum of squares) as an EXACT ACCUMULATOR (round 5, ABI 6): cs_bn_accum_words(C) = 6 C + 1
+ * zero-initialised 8-byte words -- every contribution is split into three fixed-point limbs (weights 2^10, 2^-40, 2^-90) that are added
+ * with integer atomics, so the totals do not depend on the order the workgroups arrive in (two runs of one step give the same bits;
+ * the reference's CPU path is deterministic too) and no bit >= 2^-90 of a contribution is lost; the last word is a sticky
+ * "a contribution was NaN / infinite / >= 2^59" flag that makes every total read as NaN.  The words are opaque: kernels of this
+ * library produce (cs_bn_stats, cs_conv2d_fwd with `stats`, cs_bn_partial_fold, cs_bn_bwd_reduce) and consume (cs_bn_finalize,
+ * cs_bn_apply_stats, cs_bn_bwd_apply) them; cs_bn_accum_read gives the two totals per channel as fp64 [2][C].  The parameters
+ * keep their historical `double*` type. */
+size_t cs_bn_accum_words(int C);
+int cs_bn_accum_read(const double* accum, int C, double* out, void* stream);
 int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream);
 /* `workspace` of cs_bn_stats / cs_bn_bwd_reduce (nullable, cs_bn_partial_workspace(M, C) bytes -- 0 where the launch has so few
- * workgroups that it adds its sums with fp64 atomics and wants none): per-workgroup partial sums are
- * written there and folded by a second small launch instead of ~1000 fp64 atomics per channel (3x faster on large tensors). */
+ * workgroups that it adds its sums straight into the accumulator and wants none): per-workgroup partial sums are
+ * written there and folded by a second small launch instead of ~1000 atomics per channel (3x faster on large tensors). */
 size_t cs_bn_partial_workspace(long long M, int C);
 /* mean, rstd = 1/sqrt(biased var+eps); running_* (nullable) updated in place with `momentum` and the
  * unbiased variance, as nn.BatchNorm2d does. */
@@ -79,13 +88,13 @@ int cs_bn_finalize(const double* stats, long long M, float eps, float momentum, 
 int cs_bn_apply(const void* z, int dtype, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream);
 /* cs_bn_finalize + cs_bn_apply in ONE launch (train-mode forward of nn.BatchNorm2d, model/resnet.py:150 / efficientnet.py:93 with
- * module.training): every thread derives mean and 1/sqrt(var + eps) of its channels from the fp64 sums `stats` [2][C] with the same
+ * module.training): every thread derives mean and 1/sqrt(var + eps) of its channels from the accumulator `stats` (above) with the same
  * arithmetic as cs_bn_finalize (bit-identical results), workgroup 0 writes mean_out / rstd_out (kept for backward) and updates the
  * running statistics (nullable). */
 int cs_bn_apply_stats(const void* z, int dtype, const double* stats, float eps, float momentum, float* running_mean,
                       float* running_var, const float* gamma, const float* beta, const void* residual, int act, void* y,
                       float* mean_out, float* rstd_out, long long M, int C, void* stream);
-/* sums fp64 [2][C] (zeroed by caller): sum g, sum g*xhat with xhat=(z-mean)*rstd and g = dy, or for
+/* sums: an exact accumulator like `stats` above (cs_bn_accum_words(C) zeroed words): sum g, sum g*xhat with xhat=(z-mean)*rstd and g = dy, or for
  * act==CS_ACT_SILU g = dy*silu'(gamma*xhat+beta) (the activation that follows the BN; ReLU gradients are
  * already masked by the consumers, see engine.py). gamma/beta nullable (1/0).
  * Two flags may be OR-ed into `act` of cs_bn_bwd_reduce / cs_bn_bwd_apply (the BatchNorm1d layers of the image heads,
@@ -138,7 +147,7 @@ int cs_stage_conv_bn_multi(const CsStageDesc* desc, int n, int total_blocks, int
  * forward: y = act( scale[k]*conv(x,w) + shift[k] + residual ), any of scale/shift/residual NULL.
  *   Fuses Conv2d+BatchNorm2d(eval)+ReLU(+residual add) of BasicBlock/Bottleneck.forward
  *   (resnet.py:28-43, 60-78) and Conv2d(bias) of upsample_conv/seg_out_conv (resnet.py:195-200,164).
- *   stats (nullable, fp64 [2][K], needs `workspace`): accumulates sum and sum of squares of the STORED output per channel
+ *   stats (nullable, an exact accumulator of cs_bn_accum_words(K) zeroed words -- see cs_bn_stats --, needs `workspace`): accumulates sum and sum of squares of the STORED output per channel
  *   (BatchNorm2d train-mode batch statistics). */
 int cs_conv2d_fwd(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale,
                   const float* shift, const void* residual, int act, void* y, double* stats, void* workspace,
@@ -170,7 +179,8 @@ int cs_conv2d_dgrad_bits(const CsConvGeom* g, int dtype, const void* dy, const v
                          const uint8_t* mask_bits, void* dx, float* colsum, void* workspace, void* stream);
 /* Deferred column sums: with colsum == NULL and workspace != NULL (stride-1, ungrouped launches only) cs_conv2d_dgrad leaves the
  * per-workgroup partial rows in `workspace` -- row r holds the sums of destination-pixel tile r at [r * 2*C + c] -- and skips the
- * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows);
+ * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows, in a
+ * fixed order: the unused second half of the first <= 32 partial rows serves as scratch, so `partial` is written to);
  * cs_wgrad_finalize_batched takes the partial rows as they are and folds each channel's column inside its own launch. */
 int cs_conv2d_dgrad_partial_rows(const CsConvGeom* g);
 int cs_fold_partial_rows(const float* partial, int rows, int n_out, float* out, void* stream);
@@ -296,7 +306,8 @@ int cs_dwconv_fwd(const CsConvGeom* g, int dtype, const void* x, const float* w_
                   int act, void* y, void* stream);
 /* Depthwise forward for train-mode BN: y = raw conv output, and the per-channel sum / sum of squares of the stored y as
  * *partial_rows per-workgroup rows partial[r][2][C] (fp64, cs_dwconv_fwd_stats_workspace(g) bytes); cs_bn_partial_fold adds the
- * rows into stats[2][C] (zeroed by the caller) -- together they replace cs_dwconv_fwd + cs_bn_stats (one pass over y less). */
+ * rows into the exact accumulator `stats` (cs_bn_accum_words(C) zeroed words) -- together they replace cs_dwconv_fwd + cs_bn_stats
+ * (one pass over y less). */
 size_t cs_dwconv_fwd_stats_workspace(const CsConvGeom* g);
 int cs_dwconv_fwd_stats(const CsConvGeom* g, int dtype, const void* x, const float* w_hwc, void* y, double* partial,
                         int* partial_rows, void* stream);
@@ -345,7 +356,9 @@ int cs_softmax_argmax(const float* logits, int64_t* idx, int M, int C, void* str
 int cs_mse(const float* x, const float* t, int weighted, int mean, float* loss, float* dx, int M, void* stream);
 
 /* Dice loss (train/losses.py:44-62 over metrics/metrics.py:36-53) on p[N][HW], t[N][HW] fp32:
- * sums fp64 [N][3] = (sum p*t, sum p^2, sum t^2); loss = mean|sum over n of 1-(2a+eps)/(b+c+eps). */
+ * sums = (sum p*t, sum p^2, sum t^2) per sample as an exact accumulator (see cs_bn_stats) of cs_bn_accum_words(3 N) 8-byte words,
+ * cleared by cs_dice_fwd (the block sums are added in any order with the same bits: the reference's CPU path repeats too);
+ * loss = mean|sum over n of 1-(2a+eps)/(b+c+eps). */
 int cs_dice_fwd(const float* p, const float* t, int N, long long HW, float eps, int mean, double* sums, float* loss,
                 void* stream);
 int cs_dice_bwd(const float* p, const float* t, const double* sums, int N, long long HW, float eps, int mean, float* dp,

@@ -58,7 +58,8 @@ def test_depthwise_conv(cfg, dtype, dev):
     torch.cuda.synchronize()
     assert torch.equal(zs, yd)
     zf = zs.double().cpu().reshape(-1, C)
-    assert _rel(stats[0].cpu(), zf.sum(0)) < 1e-5 and _rel(stats[1].cpu(), (zf * zf).sum(0)) < 1e-5
+    sv = K.stats_values(stats)
+    assert _rel(sv[0].cpu(), zf.sum(0)) < 1e-5 and _rel(sv[1].cpu(), (zf * zf).sum(0)) < 1e-5
 
 
 def test_se_and_rowscale(dev):
@@ -143,11 +144,10 @@ def test_efficientnet_tile_and_image_vs_oracle(arch, size, n, dev):
         g, r = p.grad.cpu(), osd[k].grad
         worst.append((float((g - r).abs().max() / max(float(r.abs().max()), 1e-3 * gmax)), k))
     worst.sort(reverse=True)
-    # B3 at 96 x 96 normalises over 18 rows (n = 2, 3 x 3 pixels) in its last stages: a one-ulp difference in a batch statistic -- the
-    # reductions of <= 512 workgroups add their partial sums with fp64 atomics, in arrival order -- is amplified ~100x per such layer, and
-    # one run in ten or so lands a single tensor above 5e-3 (seen once in ~10 runs of round 4; B0 / B2, the reference's own factories,
-    # never).  The bulk of the tensors (the median) is held to 1e-3 for every network.
-    assert worst[0][0] < (2e-2 if arch == "efficientnet_b3" else 5e-3), worst[:5]
+    # (round 4 had loosened B3 to 2e-2: its batch statistics were added up with fp64 atomics in arrival order, a one-ulp difference is
+    # amplified ~100x per 18-row BatchNorm of the last stages and one run in ten landed above 5e-3.  Round 5: the statistics are exact,
+    # order-independent sums -- tests/test_determinism_gpu.py -- and the bound is 5e-3 for every network again.)
+    assert worst[0][0] < 5e-3, worst[:5]
     assert float(np.median([w for w, _ in worst])) < 1e-3
     bufs = dict(m.named_buffers())
     assert _rel(bufs["features.0.1.running_var"].cpu(), osd["features.0.1.running_var"]) < 1e-5

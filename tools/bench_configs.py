@@ -27,11 +27,13 @@ FUSED = os.environ.get("FUSED_ADAM", "1") != "0"      # graphed configs: torch's
 HIP_ADAM = os.environ.get("HIP_ADAM", "1") != "0"     # eager configs: cellsegmentation_amd.optim.Adam (one launch), as bench.py
 
 
-def make_adam(params, lr, wd):
+def make_adam(params, lr, wd, capturable=False):
+    """eager configs: cellsegmentation_amd.optim.Adam (one launch); graphed configs: the same class with its step counts on the
+    device (capturable=True, round 5) -- HIP_ADAM=0 falls back to torch's fused implementation for A/B runs."""
     if HIP_ADAM:
         from cellsegmentation_amd.optim import Adam
-        return Adam(params, lr=lr, weight_decay=wd)
-    return torch.optim.Adam(params, lr=lr, weight_decay=wd, fused=FUSED)
+        return Adam(params, lr=lr, weight_decay=wd, capturable=capturable)
+    return torch.optim.Adam(params, lr=lr, weight_decay=wd, fused=FUSED, capturable=capturable)
 
 
 def fill(m):
@@ -89,7 +91,7 @@ if "c1" in which:
     # the same step replayed as one HIP graph (cellsegmentation_amd.graphed): the eager step is host-bound (~1000 launches)
     from cellsegmentation_amd.graphed import GraphedStep
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
-    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=8e-5, weight_decay=1e-4, capturable=True, fused=FUSED)
+    optg = make_adam([p for p in m.parameters() if p.requires_grad], 8e-5, 1e-4, capturable=True)
 
     def s1g_body(xb, cb, nb):
         optg.zero_grad(set_to_none=True)
@@ -114,7 +116,7 @@ if "c2g" in which:
         opt.step()
     run("c2 resnet50 tile bag=64 bf16 --scratch (the headline step), eager", s2e, 64, "tiles/s")
     m = fill(R.MILresnet50()); m.setmode("tile"); m.set_encoder_grads(True); m.train()
-    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, capturable=True, fused=FUSED)
+    optg = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4, capturable=True)
 
     def s2g_body(xb, yb):
         optg.zero_grad(set_to_none=True)
@@ -184,7 +186,7 @@ if "c4g" in which:
     from cellsegmentation_amd.graphed import GraphedStep
     m = fill(EN.MILefficientnetB3(num_classes=2)); m.setmode("tile"); m.set_encoder_grads(True); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
-    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, capturable=True, fused=FUSED)
+    optg = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4, capturable=True)
 
     def s4g_body(xb, yb):
         optg.zero_grad(set_to_none=True)
@@ -198,7 +200,7 @@ if "c5g" in which:
     from cellsegmentation_amd.graphed import GraphedStep
     m = fill(R.MILresnet50()); m.setmode("segment"); m.train()
     x = tiles(8); mask = (torch.rand(8, 299, 299, device=dev) > 0.8).float()
-    optg = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-4, capturable=True, fused=FUSED)
+    optg = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4, capturable=True)
 
     def s5g_body(xb, mb):
         optg.zero_grad(set_to_none=True)
