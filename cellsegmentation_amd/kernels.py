@@ -899,6 +899,11 @@ def dice_fwd(p, t, eps=1e-6, mean=True):
     return loss, sums
 
 
+def dice_sums_values(sums, N):
+    """fp64 [N, 3]: the per-sample (sum p t, sum p^2, sum t^2) that dice_fwd left in its exact accumulator."""
+    return stats_values(sums)[0].view(N, 3)
+
+
 def dice_bwd(p, t, sums, eps=1e-6, mean=True):
     N, HW = p.shape
     dp = torch.empty_like(p)

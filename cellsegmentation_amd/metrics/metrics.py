@@ -19,7 +19,7 @@ class _DiceCoef(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, t, eps):
         _, sums = K.dice_fwd(p, t, eps, True)
-        s = sums.float()
+        s = K.dice_sums_values(sums, p.shape[0]).float()
         d = (2 * s[:, 0] + eps) / (s[:, 1] + s[:, 2] + eps)
         ctx.save_for_backward(p, t, s)
         ctx.eps = eps

@@ -64,6 +64,12 @@ def test_graphed_resnet50_tile_step_equals_eager_steps_bit_for_bit(bag, size, de
     assert torch.equal(l1, l2)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+    stepped = 0
     for p, q in zip(o1.param_groups[0]["params"], o2.param_groups[0]["params"]):
+        if not o1.state.get(p):                      # upconv5-8 stay trainable in every mode (resnet.py:226-232) but get no gradient here
+            assert not o2.state.get(q)
+            continue
+        stepped += 1
         assert float(o1.state[p]["step"]) == float(o2.state[q]["step"]) == 7.0
         assert torch.equal(o1.state[p]["exp_avg_sq"], o2.state[q]["exp_avg_sq"])
+    assert stepped > 150
