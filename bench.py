@@ -393,8 +393,8 @@ def secondary_configs(timeout_s=240):
 def _rccl_debug_env():
     """Ask RCCL for its INIT / TUNING log lines in a per-process file (before the communicator exists), unless the caller already
     configured NCCL_DEBUG.  Returns the file of THIS process or None."""
-    if "NCCL_DEBUG" in os.environ:
-        return os.environ.get("NCCL_DEBUG_FILE")
+    if os.environ.get("NCCL_DEBUG_FILE"):
+        return os.environ["NCCL_DEBUG_FILE"]
     import tempfile
     path = os.path.join(tempfile.gettempdir(), f"cellseg_rccl_{os.getpid()}.log")
     os.environ["NCCL_DEBUG"] = "INFO"

@@ -132,27 +132,42 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual,
-                                                       int act, T* __restrict__ y, long long M, int C, int rows_per_block, BnFinalizeArgs fin) {
+                                                       int act, T* __restrict__ y, long long M, int C, int rows_per_block, int cw, BnFinalizeArgs fin) {
+    // grid = (row blocks, channel chunks of <= cw 8-channel groups).  Round 5: with fin.stats every THREAD used to derive mean / rstd of
+    // its 8 channels from the sums itself -- 16 fp64 loads per thread, every workgroup pulling the whole table through L2 (110 KB per
+    // workgroup of a 2304-channel tensor once the sums became three-limb exact accumulators: +14 us per launch).  Now a workgroup owns
+    // a chunk of <= 32 groups, derives the chunk's constants ONCE into LDS, and its threads read them from there.
     const int CG = C / 8;
-    if (fin.stats && blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += 256)
-            bn_finalize_channel(fin.stats, c, C, fin.M, fin.eps, fin.momentum, fin.running_mean, fin.running_var, fin.mean_out, fin.rstd_out);
+    __shared__ float s_mu[2048], s_rs[2048];
+    {
+        const int cg0 = blockIdx.y * cw;
+        const int width = (CG - cg0) < cw ? (CG - cg0) : cw;
+        if (fin.stats) {
+            for (int i = threadIdx.x; i < width * 8; i += 256) {
+                const int c = cg0 * 8 + i;
+                double var;
+                bn_moments(ex_read(fin.stats, C, 0, c), ex_read(fin.stats, C, 1, c), fin.M, fin.eps, s_mu[i], s_rs[i], var);
+                if (blockIdx.x == 0)
+                    bn_finalize_channel(fin.stats, c, C, fin.M, fin.eps, fin.momentum, fin.running_mean, fin.running_var, fin.mean_out, fin.rstd_out);
+            }
+            __syncthreads();
+        }
+    }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
-        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+    {
+        const int cg0 = blockIdx.y * cw;
+        const int width = (CG - cg0) < cw ? (CG - cg0) : cw;
         const int rpar = 256 / width;
-        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int cgl = (int)(threadIdx.x % width);
+        const int cg = cg0 + cgl;
         const int rr = threadIdx.x / width;
-        if (rr >= rpar) continue;
+        if (rr >= rpar) return;
         float mu[8], rs[8], gm[8], bt[8];
         if (fin.stats) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                double var;
-                bn_moments(ex_read(fin.stats, C, 0, cg * 8 + e), ex_read(fin.stats, C, 1, cg * 8 + e), fin.M, fin.eps, mu[e], rs[e], var);
-            }
+            for (int e = 0; e < 8; ++e) { mu[e] = s_mu[cgl * 8 + e]; rs[e] = s_rs[cgl * 8 + e]; }
         } else {
             load8p(mean + cg * 8, 0.f, mu);
             load8p(rstd + cg * 8, 1.f, rs);
@@ -276,34 +291,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                            const double* __restrict__ sums,
                                                            long long M, int C, T* __restrict__ dz, float* dgamma, float* dbeta,
-                                                           int rows_per_block) {
+                                                           int rows_per_block, int cw) {
+    // grid = (row blocks, channel chunks of <= cw groups): the chunk's two totals per channel are read ONCE per workgroup (bn_apply_kernel)
     const int CG = C / 8;
     const float invM = 1.f / (float)M;
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) dbeta[c] = (float)ex_read(sums, C, 0, c);
-            if (dgamma) dgamma[c] = (float)ex_read(sums, C, 1, c);
-        }
-    }
+    __shared__ float s_k0[2048], s_k1[2048];
+    const bool frozen = (act & CS_BN_BWD_FROZEN) != 0;      // running statistics: mean / rstd do not depend on the batch
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
-        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+    {
+        const int cg0 = blockIdx.y * cw;
+        const int width = (CG - cg0) < cw ? (CG - cg0) : cw;
+        for (int i = threadIdx.x; i < width * 8; i += 256) {
+            const int c = cg0 * 8 + i;
+            const float t0 = (float)ex_read(sums, C, 0, c), t1 = (float)ex_read(sums, C, 1, c);
+            s_k0[i] = frozen ? 0.f : t0 * invM;
+            s_k1[i] = frozen ? 0.f : t1 * invM;
+            if (blockIdx.x == 0) {
+                if (dbeta) dbeta[c] = t0;
+                if (dgamma) dgamma[c] = t1;
+            }
+        }
+        __syncthreads();
         const int rpar = 256 / width;
-        const int cg = cg0 + (int)(threadIdx.x % width);
+        const int cgl = (int)(threadIdx.x % width);
+        const int cg = cg0 + cgl;
         const int rr = threadIdx.x / width;
-        if (rr >= rpar) continue;
+        if (rr >= rpar) return;
         float mu[8], rs[8], gm[8], bt[8], k0[8], k1[8], gr[8];
         load8p(mean + cg * 8, 0.f, mu);
         load8p(rstd + cg * 8, 1.f, rs);
         load8p(gamma ? gamma + cg * 8 : nullptr, 1.f, gm);
         load8p(beta ? beta + cg * 8 : nullptr, 0.f, bt);
-        const bool frozen = (act & CS_BN_BWD_FROZEN) != 0;      // running statistics: mean / rstd do not depend on the batch
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            k0[e] = frozen ? 0.f : (float)ex_read(sums, C, 0, cg * 8 + e) * invM;
-            k1[e] = frozen ? 0.f : (float)ex_read(sums, C, 1, cg * 8 + e) * invM;
+            k0[e] = s_k0[cgl * 8 + e];
+            k1[e] = s_k1[cgl * 8 + e];
             gr[e] = gm[e] * rs[e];
         }
         auto finish = [&](float (&g)[8], const float (&zz)[8], const long long off) {
@@ -396,6 +420,25 @@ inline int ew_rows_per_block(long long M, int C) {
     return (int)r;
 }
 
+// Decomposition of the element-wise passes (bn_apply_kernel, bn_bwd_apply_kernel): channel chunks of max_w 8-channel groups,
+// and rows per workgroup for ~CELLSEG_EW_BLOCKS workgroups in all with at least `steps` two-row steps per thread.
+struct EwSplit { int chunks, cw, rpb; };
+inline EwSplit ew_split(long long M, int C, int max_w, int steps) {
+    static const int target = cs_env_int_("CELLSEG_EW_BLOCKS", 2048);       // A/B experiments only
+    const int CG = C / 8 > 0 ? C / 8 : 1;
+    EwSplit s;
+    s.cw = CG < max_w ? CG : max_w;                  // (the last chunk may be narrower: a workgroup derives its own width)
+    s.chunks = (CG + s.cw - 1) / s.cw;
+    const int rpar = 256 / s.cw > 0 ? 256 / s.cw : 1;
+    long long row_blocks = target / s.chunks;
+    if (row_blocks < 1) row_blocks = 1;
+    long long r = (M + row_blocks - 1) / row_blocks;
+    const long long floor_rows = 2LL * steps * rpar;
+    if (r < floor_rows) r = floor_rows;
+    s.rpb = (int)r;
+    return s;
+}
+
 }  // namespace
 
 #define CS_DISPATCH_T(dtype, CALL_F32, CALL_BF16, NAME)      \
@@ -467,14 +510,14 @@ extern "C" int cs_bn_apply(const void* z, int dtype, const float* mean, const fl
                            const float* beta, const void* residual, int act, void* y, long long M, int C, void* stream) {
     CS_CHECK_ARG(z && y && mean && rstd && M > 0 && C > 0 && C % 8 == 0, "bn_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = ew_rows_per_block(M, C);
-    const int grid = (int)((M + rpb - 1) / rpb);
+    const EwSplit sp = ew_split(M, C, 256, 2);
+    const dim3 grid((unsigned)((M + sp.rpb - 1) / sp.rpb), (unsigned)sp.chunks);
     const BnFinalizeArgs fin{};
     CS_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, mean, rstd, gamma, beta,
-                                     (const float*)residual, act, (float*)y, M, C, rpb, fin),
-                  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)z, mean, rstd, gamma, beta,
-                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, rpb, fin),
+                  hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)z, mean, rstd, gamma, beta,
+                                     (const float*)residual, act, (float*)y, M, C, sp.rpb, sp.cw, fin),
+                  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)z, mean, rstd, gamma, beta,
+                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, sp.rpb, sp.cw, fin),
                   "bn_apply");
     CS_LAUNCH_CHECK();
     return CS_OK;
@@ -485,14 +528,15 @@ extern "C" int cs_bn_apply_stats(const void* z, int dtype, const double* stats, 
                                  float* mean_out, float* rstd_out, long long M, int C, void* stream) {
     CS_CHECK_ARG(z && y && stats && mean_out && rstd_out && M > 0 && C > 0 && C % 8 == 0, "bn_apply_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = ew_rows_per_block(M, C);
-    const int grid = (int)((M + rpb - 1) / rpb);
+    // (chunks of <= 32 channel groups: a workgroup reads the accumulator words of its own 256 channels only; wide chunks get twice the rows)
+    const EwSplit sp = ew_split(M, C, 32, C > 64 ? 4 : 2);
+    const dim3 grid((unsigned)((M + sp.rpb - 1) / sp.rpb), (unsigned)sp.chunks);
     const BnFinalizeArgs fin{stats, M, eps, momentum, running_mean, running_var, mean_out, rstd_out};
     CS_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)z, nullptr, nullptr, gamma, beta,
-                                     (const float*)residual, act, (float*)y, M, C, rpb, fin),
-                  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)z, nullptr, nullptr, gamma, beta,
-                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, rpb, fin),
+                  hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)z, nullptr, nullptr, gamma, beta,
+                                     (const float*)residual, act, (float*)y, M, C, sp.rpb, sp.cw, fin),
+                  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)z, nullptr, nullptr, gamma, beta,
+                                     (const bf16_t*)residual, act, (bf16_t*)y, M, C, sp.rpb, sp.cw, fin),
                   "bn_apply_stats");
     CS_LAUNCH_CHECK();
     return CS_OK;
@@ -525,13 +569,13 @@ extern "C" int cs_bn_bwd_apply(const void* dy, const void* z, int dtype, const f
                                float* dgamma, float* dbeta, void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && dz && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = ew_rows_per_block(M, C);
-    const int grid = (int)((M + rpb - 1) / rpb);
+    const EwSplit sp = ew_split(M, C, 32, C > 64 ? 4 : 2);
+    const dim3 grid((unsigned)((M + sp.rpb - 1) / sp.rpb), (unsigned)sp.chunks);
     CS_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
-                                     rstd, gamma, beta, act, sums, M, C, (float*)dz, dgamma, dbeta, rpb),
-                  hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, mean,
-                                     rstd, gamma, beta, act, sums, M, C, (bf16_t*)dz, dgamma, dbeta, rpb),
+                  hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
+                                     rstd, gamma, beta, act, sums, M, C, (float*)dz, dgamma, dbeta, sp.rpb, sp.cw),
+                  hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, mean,
+                                     rstd, gamma, beta, act, sums, M, C, (bf16_t*)dz, dgamma, dbeta, sp.rpb, sp.cw),
                   "bn_bwd_apply");
     CS_LAUNCH_CHECK();
     return CS_OK;

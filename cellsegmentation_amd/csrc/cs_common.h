@@ -117,37 +117,39 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 // ---- exact, order-independent accumulation (round 5: deterministic batch statistics) --------------------------------------------
 // The per-channel sums of a train-mode BatchNorm (sum z / sum z^2, sum g / sum g*xhat) are added up from hundreds of workgroups.  With
-// floating-point atomics the result depends on the order the workgroups arrive in: two runs of the same step gave different bits
-// (VERDICT r4 weak 1).  Here every contribution is split into three signed fixed-point limbs of weight 2^10, 2^-40 and 2^-90
-// (50 bits each) that are added with INTEGER atomics -- integer addition is associative, so the total is the same in any order, and
-// it is exact: every bit of a contribution at or above 2^-90 is kept (<= 2^12 contributors of < 2^50 per limb fit 63 bits).
+// plain floating-point atomics the result depends on the order the workgroups arrive in: two runs of the same step gave different
+// bits.  Here every contribution t (|t| < 2^40) is split into three LIMBS that are multiples of 2^0, 2^-40 and
+// 2^-80 and smaller than 2^40 times their unit: l2 = trunc(t), l1 = trunc((t - l2) 2^40) 2^-40, l0 = rint((t - l2 - l1) 2^80) 2^-80.
+// Each limb is accumulated with an fp64 atomic add of its own: up to 2^12 contributors keep every partial sum of a limb a multiple
+// of its unit below 2^53 units, i.e. EXACTLY representable -- every addition is exact, so the total is the same in any order, and no
+// bit of a contribution at or above 2^-80 is lost.  (A first version with three int64 limbs was as exact but cost the consumers
+// -- every thread of the apply passes reads 16 totals -- 48 emulated int64 -> fp64 conversions: C4 3.35 -> 3.06 k tiles/s.)
 // Accumulator of a C-channel tensor: cs_bn_accum_words(C) = 6 C + 1 zero-initialised 8-byte words,
-//   word (2 * limb + which) * C + c   limb 0..2 of sum `which` (0: first sum, 1: second sum) of channel c
-//   word 6 C                          sticky flag: a contribution was NaN / infinite / >= 2^59 -> every total reads as NaN
-// (declared `double*` in the C ABI for history: the words are opaque to callers; cs_bn_accum_read gives the totals as doubles).
+//   word (2 * limb + which) * C + c   limb 0..2 (units 2^-80, 2^-40, 2^0) of sum `which` (0: first sum, 1: second sum) of channel c
+//   word 6 C                          sticky flag: a contribution was NaN / infinite / >= 2^40 -> every total reads as NaN
 constexpr int kExLimbs = 3;
 __host__ __device__ inline long long ex_words(int C) { return 6LL * C + 1; }
 __device__ __forceinline__ void ex_add(void* acc, int C, int which, int c, double t) {
-    unsigned long long* w = reinterpret_cast<unsigned long long*>(acc);
-    if (!(fabs(t) < 0x1p59)) {                      // NaN, infinity or out of range
-        atomicOr(w + 6LL * C, 1ull);
+    double* w = reinterpret_cast<double*>(acc);
+    if (!(fabs(t) < 0x1p40)) {                      // NaN, infinity or out of range
+        atomicOr(reinterpret_cast<unsigned long long*>(w + 6LL * C), 1ull);
         return;
     }
-    const double l2 = trunc(t * 0x1p-10);
-    const double r1 = t - l2 * 0x1p10;              // exact: the bits of t below 2^10
-    const double l1 = trunc(r1 * 0x1p40);
-    const double r0 = r1 - l1 * 0x1p-40;            // exact: the bits below 2^-40
-    const double l0 = rint(r0 * 0x1p90);
-    unsigned long long* p = w + (long long)which * C + c;
-    if (l0 != 0.0) atomicAdd(p, (unsigned long long)(long long)l0);
-    if (l1 != 0.0) atomicAdd(p + 2LL * C, (unsigned long long)(long long)l1);
-    if (l2 != 0.0) atomicAdd(p + 4LL * C, (unsigned long long)(long long)l2);
+    const double l2 = trunc(t);
+    const double r1 = t - l2;                       // exact: the fraction of t
+    const double l1 = trunc(r1 * 0x1p40) * 0x1p-40;
+    const double r0 = r1 - l1;                      // exact: the bits below 2^-40
+    const double l0 = rint(r0 * 0x1p80) * 0x1p-80;
+    double* p = w + (long long)which * C + c;
+    if (l0 != 0.0) atomicAdd(p, l0);
+    if (l1 != 0.0) atomicAdd(p + 2LL * C, l1);
+    if (l2 != 0.0) atomicAdd(p + 4LL * C, l2);
 }
 __device__ __forceinline__ double ex_read(const void* acc, int C, int which, int c) {
-    const long long* w = reinterpret_cast<const long long*>(acc);
-    const long long* p = w + (long long)which * C + c;
-    const double v = (double)p[4LL * C] * 0x1p10 + ((double)p[2LL * C] * 0x1p-40 + (double)p[0] * 0x1p-90);
-    return w[6LL * C] ? __longlong_as_double(0x7ff8000000000000LL) : v;
+    const double* w = reinterpret_cast<const double*>(acc);
+    const double* p = w + (long long)which * C + c;
+    const double v = p[4LL * C] + (p[2LL * C] + p[0]);
+    return reinterpret_cast<const unsigned long long*>(w)[6LL * C] ? __longlong_as_double(0x7ff8000000000000LL) : v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {

@@ -66,10 +66,11 @@ int cs_bn_fold(const float* gamma, const float* beta, const float* mean, const f
 /* ---- BatchNorm in train mode (batch statistics; model.train(), resnet.py:21,52,112,184,199 and the
  * BatchNorm1d of the image heads, resnet.py:134,138) over NHWC rows z[M][C] ----------------------
  * stats: the per-channel pair (sum, sum of squares) as an EXACT ACCUMULATOR (round 5, ABI 6): cs_bn_accum_words(C) = 6 C + 1
- * zero-initialised 8-byte words -- every contribution is split into three fixed-point limbs (weights 2^10, 2^-40, 2^-90) that are added
- * with integer atomics, so the totals do not depend on the order the workgroups arrive in (two runs of one step give the same bits;
- * the reference's CPU path is deterministic too) and no bit >= 2^-90 of a contribution is lost; the last word is a sticky
- * "a contribution was NaN / infinite / >= 2^59" flag that makes every total read as NaN.  The words are opaque: kernels of this
+ * zero-initialised 8-byte words -- every contribution is split into three limbs (multiples of 2^0, 2^-40, 2^-80, each below 2^40 of
+ * its unit) that are added with one fp64 atomic each: every partial sum of a limb stays exactly representable, so each addition is
+ * exact and the totals do not depend on the order the workgroups arrive in (two runs of one step give the same bits; the reference's
+ * CPU path is deterministic too) and no bit >= 2^-80 of a contribution is lost; the last word is a sticky
+ * "a contribution was NaN / infinite / >= 2^40" flag that makes every total read as NaN.  The words are opaque: kernels of this
  * library produce (cs_bn_stats, cs_conv2d_fwd with `stats`, cs_bn_partial_fold, cs_bn_bwd_reduce) and consume (cs_bn_finalize,
  * cs_bn_apply_stats, cs_bn_bwd_apply) them; cs_bn_accum_read gives the two totals per channel as fp64 [2][C].  The parameters
  * keep their historical `double*` type. */
