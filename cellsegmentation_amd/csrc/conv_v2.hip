@@ -1493,17 +1493,18 @@ int pick_wide_tm(long long M, int n_ntiles, int ncc) {
     if (knob == 4 || knob == 6 || knob == 8) return knob;
     if (ncc < 2) return 0;
     int best = 0;
+    const long long cus = cs_device_cus_();            // one workgroup per compute unit: `cus` run at once
     long long best_cost = 1ll << 60, best_tiles = 0;
     for (int tm = 8; tm >= 4; tm -= 2) {
         const long long tiles = ((M + 32 * tm - 1) / (32 * tm)) * n_ntiles;
-        const long long cost = ((tiles + 255) / 256) * tm;
+        const long long cost = ((tiles + cus - 1) / cus) * tm;
         if (cost < best_cost) { best_cost = cost; best = tm; best_tiles = tiles; }
     }
     // Measured (tools/wide_ab.sh, profiles/round4_notes.md): with every tile resident at once -- one round -- the wide kernel is ahead
     // of two 4-wave halo workgroups per compute unit (ResNet-50 layer3 34.2 -> 31.0 us, layer4 41.8 -> 33.9 us, decoder 1024 -> 512
     // 106 -> 96 us); with a second round its serial prologue and epilogue are paid twice with nothing to hide them behind
     // (layer2: 32.7 -> 40.2 us), and the halo kernel stays.
-    return best_tiles <= 256 ? best : 0;
+    return best_tiles <= cus ? best : 0;
 }
 
 // Pixel-tile height of the 1 x 4 halo configuration.  Workgroups do not run in lock-step rounds, so a shorter tile only pays
@@ -1528,13 +1529,14 @@ int pick_wide1_tm(long long M, int n_ntiles, int ncc) {
     if (knob == 4 || knob == 6) return knob;
     if (ncc < 8) return 0;
     int best = 0;
+    const long long cus = cs_device_cus_();
     long long best_cost = 1ll << 60, best_tiles = 0;
     for (int tm = 6; tm >= 4; tm -= 2) {               // (three LDS stages: 3 x 8 KiB x tm per wave column -- 144 KiB at tm = 6)
         const long long tiles = ((M + 32 * tm - 1) / (32 * tm)) * n_ntiles;
-        const long long cost = ((tiles + 255) / 256) * tm;
+        const long long cost = ((tiles + cus - 1) / cus) * tm;
         if (cost < best_cost) { best_cost = cost; best = tm; best_tiles = tiles; }
     }
-    return best_tiles <= 256 ? best : 0;
+    return best_tiles <= cus ? best : 0;
 }
 
 const bool g_v2_off = cs_env_flag_("CELLSEG_NO_V2");     // A/B flavour only
@@ -1648,7 +1650,7 @@ int pick_ring_tm(long long M, int n_ntiles, int ncc) {
     return (wg4 > 256 && wg4 <= 512 && wg3 <= 512) ? 3 : 4;
 }
 
-bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl, bool allow_wide = true) {
+bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl) {
     if (g_v2_off) return false;
     if (g->groups > 1) return false;
     if (g->R != 1 || g->S != 1 || g->pad != 0 || g->stride < 1) return false;
@@ -1698,7 +1700,7 @@ bool plan_gemm(const CsConvGeom* g, int dgrad, C2Plan& pl, bool allow_wide = tru
     pl.tm = cfg == 6 ? pick_ring_tm(M, p.n_ntiles, ncc) : 2;
     pl.rows = cfg == 6 ? cs_ceil_div(M, 32 * pl.tm) : cs_ceil_div(M, 128) * 2;
     pl.t2d = 0;
-    if (cfg == 6 && allow_wide && p.stride == 1 && !compact && ncc % 4 == 0) {      // (two chunks per stage, two stages per loop body)
+    if (cfg == 6 && p.stride == 1 && !compact && ncc % 4 == 0) {      // (two chunks per stage, two stages per loop body)
         const int wtm = pick_wide1_tm(M, p.n_ntiles, ncc);
         if (wtm) {
             pl.cfg = 8; pl.tm = wtm; pl.nbw = wtm;          // 2 planes x 32 * tm rows = 4 * tm blocks of 16 rows, tm per wave

@@ -40,3 +40,18 @@ extern "C" int cs_allow_dynamic_lds_(const void* fn, size_t bytes, size_t limit)
     if (n_done < 512) { done[n_done].fn = fn; done[n_done].dev = dev; ++n_done; }
     return 1;
 }
+
+// compute units of the CURRENT device (cached per device; 256 -- a whole MI355X -- when the query fails, e.g. no GPU in a build
+// container): the launch rules that ask "are all tiles resident at once?" must not assume an unpartitioned chip
+extern "C" int cs_device_cus_(void) {
+    static std::mutex mu;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}

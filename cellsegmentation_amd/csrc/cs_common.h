@@ -59,6 +59,10 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 // ReLU of two packed bf16 values: the sign bit of a bf16 is the sign bit of its int16 pattern, so max(x, 0) as signed 16-bit integers
 // clears negative values (and -0.0) and keeps positive ones -- the same result as rounding max(x, 0.f), one instruction per pair.
+// NaN: a NaN with the sign bit CLEAR passes through (as torch.relu propagates it), one with the sign bit SET becomes 0 -- sign-dependent,
+// unlike the fp32 form `v > 0 ? v : 0` (every NaN -> 0) of rounds 1-3.  The arithmetic of this library produces the canonical quiet
+// NaN 0x7fc0 (sign clear: v_cvt_pk_bf16_f32 of an fp32 NaN from MFMA / FMA inputs), so a diverging run still shows NaN downstream;
+// the batch-statistics accumulators carry their own sticky non-finite flag (ex_add).
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t x) {
     uint32_t u;
     asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(x));
@@ -186,6 +190,8 @@ static inline int cs_ceil_div(long long a, long long b) { return (int)((a + b - 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel AND per device (hipFuncSetAttribute applies to the device that is current
 // at the call).  cs_api.cpp keeps the (device, function) table under a mutex; `limit` is the byte count to allow (<= 160 KiB).
 extern "C" int cs_allow_dynamic_lds_(const void* fn, size_t bytes, size_t limit);
+// compute units of the current device (cs_api.cpp; 256 when the query fails)
+extern "C" int cs_device_cus_(void);
 
 // A/B knobs.  The production library (`make`) has none: every knob is its default, nothing reads the environment and
 // cs_set_igemm_path is not exported.  `make AB=1` (-DCS_AB_SWITCHES -> libcellseg_hip_ab.so, loaded by the forced-mode tests and
