@@ -124,8 +124,8 @@ def _traffic_for(name, by_per_launch, cfg=None):
     """HBM bytes per launch from the committed PMC passes (tools/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs,
     gfx950-corrected), newest round first; None when the kernel was not sampled.  `cfg`: the passes of a secondary config
     (tools/bench_configs.py c4 / c5 / c5x) instead of the headline step's."""
-    files = ([f"round{r}_traffic_{cfg}.json" for r in (4, 3)] if cfg
-             else ["round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"])
+    files = ([f"round{r}_traffic_{cfg}.json" for r in (5, 4, 3)] if cfg
+             else [f"round{r}_traffic.json" for r in (5, 4, 3, 2, 1)])
     for fn in files:
         tpath = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(tpath):

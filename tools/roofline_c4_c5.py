@@ -14,7 +14,7 @@ import os
 import re
 import sys
 
-ROUND = int(__import__("os").environ.get("ROUND", "4"))
+ROUND = int(__import__("os").environ.get("ROUND", "5"))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -105,7 +105,7 @@ def summed(tab, traf, pat):
 
 def main():
     P = os.path.join(ROOT, "profiles")
-    out = ["# Round 3 -- per-kernel rooflines of C4 and C5 (`python tools/roofline_c4_c5.py`)", "",
+    out = [f"# Round {ROUND} -- per-kernel rooflines of C4 and C5 (`ROUND={ROUND} python tools/roofline_c4_c5.py`)", "",
            "peak: HBM 8000 GB/s (spec; ~6300 achievable), dense bf16 MFMA 2500 TFLOP/s.  `achieved` = algorithmic bytes (or FLOPs) per step / "
            "kernel time per step from the rocprofv3 table; `traffic` = HBM bytes per step from the FETCH_SIZE / WRITE_SIZE passes (read side x2).", ""]
     # ---------------- C4
@@ -161,17 +161,23 @@ def main():
         out += [f"## {title} (GPU time {total:.2f} ms/step)", "",
                 f"decoder 3x3 convolutions: {tot / 1e9:.0f} GFLOP forward per step ({sum(fl[6:]) / 1e9:.0f} of them in the two widest layers).", "",
                 "| kernel(s) | launches/step | ms/step | bound | algorithmic | achieved | frac | traffic |", "|---|---:|---:|---|---|---|---:|---|"]
-        c, ms, tb = summed(tab, tr, r"^conv2_halo_kernel")
-        # (the frozen encoder's stride-1 3x3 forwards run on the same kernel: 16 launches, ~0.16 of the forward FLOPs of a 299 x 299 image)
+        # the second-generation stride-1 3x3 kernels: halo AND (round 4 on) the one-wave-per-SIMD wide kernel in its 9-tap form, which serves
+        # the layers whose tiles are all resident at once -- round 4's table priced the halo launches alone against all the FLOPs
+        S1_3X3 = r"^conv2_halo_kernel|^conv2_wide_kernel<\d+,\d+,(true|false),9>"
+        c, ms, tb = summed(tab, tr, S1_3X3)
+        # (the frozen encoder's stride-1 3x3 forwards run on the same kernels: 16 launches, ~0.16 of the forward FLOPs of a 299 x 299 image)
         enc3 = 2.0 * n * 9 * sum(cc * cc * ss * ss * rep for cc, ss, rep in ((128, (hw + 7) // 8, 3), (256, (hw + 15) // 16, 5), (512, (hw + 31) // 32, 2)))
-        out.append(line("conv2_halo_kernel<9,3,..> (decoder forward + data gradient, the encoder's stride-1 3x3 forwards)", c, ms, alg_tf=halo_fl + enc3, traf=tb))
+        out.append(line("conv2_halo_kernel<9,3,..> + conv2_wide_kernel<..,9> (decoder forward + data gradient, the encoder's stride-1 3x3 forwards)", c, ms, alg_tf=halo_fl + enc3, traf=tb))
+        ch_, msh_, _ = summed(tab, tr, r"^conv2_halo_kernel")
+        cw_, msw_, _ = summed(tab, tr, r"^conv2_wide_kernel<\d+,\d+,(true|false),9>")
+        out.append(f"| (of which halo: {ch_:.0f} launches, {msh_:.3f} ms; wide: {cw_:.0f} launches, {msw_:.3f} ms) | | | | | | | |")
         c, ms, tb = summed(tab, tr, r"^wgrad2_kernel")
         out.append(line("wgrad2_kernel<..> (decoder weight gradients)", c, ms, alg_tf=w2_fl, traf=tb))
         c1, ms1, tb1 = summed(tab, tr, r"^igemm_dma_kernel<bf16,\d+,\d+,1,")
         out.append(line("igemm_dma_kernel<..,1,..> (first generation: upconv8 forward, the encoder's three strided and three 64-channel 3x3)", c1, ms1, traf=tb1))
         c2, ms2, tb2 = summed(tab, tr, r"^wgrad_dma_kernel|^wgrad_spec_kernel")
         out.append(line("wgrad_dma / wgrad_spec (first generation weight gradients)", c2, ms2, traf=tb2))
-        ch, msh, _ = summed(tab, tr, r"^conv2_halo_kernel")
+        ch, msh, _ = summed(tab, tr, S1_3X3)
         cw, msw, _ = summed(tab, tr, r"^wgrad2_kernel")
         fam_ms = msh + msw + ms1 + ms2
         out += ["", f"3x3 family (all four rows: {3 * sum(fl) / 1e9:.0f} GFLOP decoder fwd + dgrad + wgrad, {enc3 / 1e9:.0f} GFLOP encoder stride-1 forwards; the encoder's three strided 3x3 forwards only in the "
