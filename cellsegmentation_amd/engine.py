@@ -515,12 +515,16 @@ def _geom_key(geom):
 
 
 def _defers(u, a, need, ui):
-    """Ungrouped, bias-free convolutions take the batched weight-gradient path: eval-BN layers whose weight AND BN gradients are wanted
-    (the finalize also writes dgamma / dbeta), and batch-statistics layers whose weight gradient is wanted (their BN gradients come
-    from the BN backward pass; the finalize only folds the slabs)."""
-    if not (u.kind == "conv" and need(ui, "weight") and not need(ui, "bias") and not u.grouped and u.bn is not None and u.conv.bias is None):
+    """Ungrouped convolutions under a BatchNorm take the batched weight-gradient path (one split-K launch + ONE fused finalize per group of
+    identical geometry; the fused finalize turns the [rs][c] slabs into torch's [c][rs] order through LDS): eval-BN layers without a
+    bias whose weight AND BN gradients are wanted (the finalize also writes dgamma / dbeta), and batch-statistics layers whose weight
+    gradient is wanted (their BN gradients come from the BN backward pass; the finalize only folds the slabs) -- round 5: also the
+    biased 3x3 convolutions of the decoder (resnet.py:195-200), whose bias gradient is the column sum of dz, taken on its own."""
+    if not (u.kind == "conv" and need(ui, "weight") and not u.grouped and u.bn is not None):
         return False
-    return True if a.train else bool(need(ui, "gamma") or need(ui, "beta"))
+    if a.train:
+        return True
+    return u.conv.bias is None and not need(ui, "bias") and bool(need(ui, "gamma") or need(ui, "beta"))
 
 
 def _group_key(geom, a):
@@ -711,6 +715,12 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
                         gsum = K.colsum_partial(dz)
                     if u.res is not None and grads.get(u.res) is g:
                         gsum_cache[u.res] = gsum
+                elif want_b:
+                    # the bias of a convolution in front of a batch-statistics BN: d bias = column sums of dz (analytically zero --
+                    # the BN backward removes the batch mean --, the reference computes the same rounding noise: train_seg.py decoder)
+                    dbias = grad_buffer(conv.bias)
+                    dbias.copy_(K.colsum(dz)[:Kc])
+                    emit(ui, "bias", dbias)
                 key = _group_key(geom, a)
                 items = deferred.setdefault(key, [])
                 items.append(SimpleNamespace(ui=ui, u=u, a=a, x=x, dz=dz, gsum=gsum))
