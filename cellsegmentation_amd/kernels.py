@@ -591,8 +591,8 @@ _stats_pools = {}
 
 
 def accum_words(C):
-    """8-byte words of the exact per-channel accumulator of a C-channel BatchNorm reduction (cs_bn_accum_words: three integer limbs
-    per sum and channel + one flag word; order-independent adds, so batch statistics repeat bit for bit)."""
+    """8-byte words of the exact per-channel accumulator of a C-channel BatchNorm reduction (cs_bn_accum_words: three fp64 limbs per sum
+    and channel, each added to exactly, + one flag word; order-independent adds, so batch statistics repeat bit for bit)."""
     return 6 * C + 1
 
 
