@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     li = wave_sum(li);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+    // the workgroups' sums meet in an exact accumulator behind the result (loss[2 ..]: any arrival order, same bits); loss_finish_kernel
+    // rounds the total into loss[0]
+    if (threadIdx.x == 0) ex_add(loss + 2, 1, 0, 0, (double)((red[0] + red[1]) + (red[2] + red[3])));
 }
 
 __global__ void softmax_prob1_kernel(const float* __restrict__ logits, float* __restrict__ p1, int M, int C) {
@@ -275,9 +277,13 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, c
     li = wave_sum(li);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+    // the workgroups' sums meet in an exact accumulator behind the result (loss[2 ..]: any arrival order, same bits); loss_finish_kernel
+    // rounds the total into loss[0]
+    if (threadIdx.x == 0) ex_add(loss + 2, 1, 0, 0, (double)((red[0] + red[1]) + (red[2] + red[3])));
 }
 
+
+__global__ void loss_finish_kernel(float* __restrict__ loss) { loss[0] = (float)ex_read(loss + 2, 1, 0, 0); }
 
 // ---- Dice (train/losses.py:44-62, metrics/metrics.py:36-53): per-sample a=sum p*t, b=sum p^2, c=sum t^2
 __global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ p, const float* __restrict__ t, long long HW,
@@ -429,12 +435,18 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
     return CS_OK;
 }
 
+// floats behind a loss value: [0] the result, [1] unused, [2 .. 15] an exact accumulator of one channel (7 eight-byte words)
+constexpr int kLossWords = 16;
+extern "C" int cs_loss_words(void) { return kLossWords; }
+
 extern "C" int cs_softmax_ce(const float* logits, const int64_t* labels, float gamma, float* loss, float* dlogits, int M, int C,
                              void* stream) {
     CS_CHECK_ARG(logits && labels && loss && M > 0 && C > 1, "softmax_ce: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { cs_set_error_("softmax_ce: memset failed"); return CS_ERR_LAUNCH; }
+    if (hipMemsetAsync(loss, 0, sizeof(float) * kLossWords, st) != hipSuccess) { cs_set_error_("softmax_ce: memset failed"); return CS_ERR_LAUNCH; }
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, logits, labels, gamma, loss, dlogits, M, C);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, loss);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }
@@ -458,9 +470,11 @@ extern "C" int cs_softmax_argmax(const float* logits, int64_t* idx, int M, int C
 extern "C" int cs_mse(const float* x, const float* t, int weighted, int mean, float* loss, float* dx, int M, void* stream) {
     CS_CHECK_ARG(x && t && loss && M > 0, "mse: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) { cs_set_error_("mse: memset failed"); return CS_ERR_LAUNCH; }
+    if (hipMemsetAsync(loss, 0, sizeof(float) * kLossWords, st) != hipSuccess) { cs_set_error_("mse: memset failed"); return CS_ERR_LAUNCH; }
     const float inv = mean ? 1.f / (float)M : 1.f;
     hipLaunchKernelGGL(mse_kernel, dim3((M + 255) / 256), dim3(256), 0, st, x, t, weighted, inv, loss, dx, M);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, loss);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -374,9 +374,10 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_kernel(const float* __re
     const int per = Cin * RS;
     // threads walk the SLAB's own [rs][c] order: coalesced reads of the nsplit partials (the bulk of the traffic);
     // the single write per weight lands RS-strided in torch's [c][rs] order
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float contrib = 0.f;
-    if (i < per) {
+    // grid-stride over the row: with a dot product wanted the launcher starts ONE workgroup per row, which then owns dot[k] (several
+    // workgroups per row added their shares with a float atomic: the BN gradient of an eval-mode layer did not repeat bit for bit)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
         const int rs = i / Cin, c = i - rs * Cin;
         const int j = c * RS + rs;
         const long long src = Cg_slab ? ((long long)k * RS + rs) * 64 + ((k % 64) / Cg_slab) * Cg_slab + c
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_kernel(const float* __re
         for (; z < nsplit; ++z) a8[0] += dw_khwc[z * slab_stride + src];
         const float raw = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         const long long o = (long long)k * per + j;
-        if (dot) contrib = w[o] * raw;
+        if (dot) contrib += w[o] * raw;
         const float val = (scale ? scale[k] : 1.f) * raw;
         dw[o] = accumulate ? dw[o] + val : val;
     }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_a_kernel(const float* __re
         contrib = wave_sum(contrib);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dot + k, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) dot[k] += (red[0] + red[1]) + (red[2] + red[3]);       // gridDim.x == 1: the only writer
     }
 }
 
@@ -688,7 +689,7 @@ static int finalize_common(const float* raw, int nsplit, long long slab_stride, 
                            float* dgamma, float* dbeta, float* dot_ws, int accumulate, hipStream_t st) {
     float* dot = dgamma ? dot_ws : nullptr;      // zeroed by the caller
     const int per = Cin * RS;
-    hipLaunchKernelGGL(wgrad_finalize_a_kernel, dim3((per + 255) / 256, K), dim3(256), 0, st, raw, w, scale, Cin, RS, Cp, Cg_slab, dw, dot,
+    hipLaunchKernelGGL(wgrad_finalize_a_kernel, dim3(dot ? 1 : (per + 255) / 256, K), dim3(256), 0, st, raw, w, scale, Cin, RS, Cp, Cg_slab, dw, dot,
                        accumulate, nsplit, slab_stride);
     CS_LAUNCH_CHECK();
     if (dgamma || dbeta || dbias) {

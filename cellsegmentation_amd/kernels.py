@@ -838,6 +838,7 @@ def gap_bwd(dfeat, argmax, x, relu_mask, with_max=True):
 
 
 # ---------------------------------------------------------------- heads / losses
+_LOSS_WORDS = 16            # cs_loss_words(): floats behind a CE / MSE value (the value + the exact accumulator of its partial sums)
 def linear_fwd(x, w, b, act=CS_ACT_NONE, want_preact=False):
     M, K = x.shape
     N = w.shape[0]
@@ -860,10 +861,10 @@ def linear_bwd(x, w, dy, y=None, act=CS_ACT_NONE, need_dx=True, need_dw=True, ne
 
 def softmax_ce(logits, labels, gamma=1.0, want_grad=True):
     M, C = logits.shape
-    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    loss = torch.empty((_LOSS_WORDS,), dtype=torch.float32, device=logits.device)      # [0] = the value, the rest: its exact accumulator
     dl = torch.empty_like(logits) if want_grad else None
     _lib.check(_lib.load().cs_softmax_ce(_p(logits), _p(labels), float(gamma), _p(loss), _p(dl), M, C, _stream()), "softmax_ce")
-    return loss, dl
+    return loss[:1], dl
 
 
 def softmax_prob1(logits):
@@ -883,10 +884,10 @@ def softmax_argmax(logits):
 
 def mse(x, t, weighted=False, mean=True, want_grad=True):
     M = x.numel()
-    loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+    loss = torch.empty((_LOSS_WORDS,), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x) if want_grad else None
     _lib.check(_lib.load().cs_mse(_p(x), _p(t), 1 if weighted else 0, 1 if mean else 0, _p(loss), _p(dx), M, _stream()), "mse")
-    return loss, dx
+    return loss[:1], dx
 
 
 def dice_fwd(p, t, eps=1e-6, mean=True):

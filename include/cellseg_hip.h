@@ -344,7 +344,10 @@ int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, floa
  * activation: `y` = stored output for ReLU / sigmoid, stored PRE-activation for SiLU. */
 int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
                   float* db, int M, int N, int K, int accumulate, void* stream);
-/* CrossEntropyLoss(mean) * gamma on logits[M][C]; loss: 1 fp32 (overwritten); dlogits nullable. */
+/* CrossEntropyLoss(mean) * gamma on logits[M][C]; dlogits nullable.  `loss` (here and in cs_mse): cs_loss_words() = 16 floats, all
+ * overwritten -- the value in loss[0], the rest is the exact accumulator the workgroups' partial sums meet in (round 5: the value of a
+ * launch with more than one workgroup no longer depends on their arrival order). */
+int cs_loss_words(void);
 int cs_softmax_ce(const float* logits, const int64_t* labels, float gamma, float* loss, float* dlogits, int M, int C,
                   void* stream);
 /* softmax(logits,1)[:,1] (inference.py:24-27) */

@@ -100,3 +100,37 @@ def test_c5_segmentation_step_repeats_bit_for_bit(arch, n, size, dev):
     g = torch.Generator().manual_seed(3)
     mask = (torch.rand((n, size, size), generator=g) > 0.8).float().to(dev)
     _assert_same(*_twice(m, lambda: HF.dice_loss(HF.softmax_channel(m(x), 1), mask)))
+
+
+def test_resnext50_tile_step_repeats_bit_for_bit(dev):
+    """Grouped 3x3 convolutions (model/resnext.py:76-91): float column sums of the grouped data gradients and the per-row dot products
+    of the stand-alone finalize were atomic sums in rounds 1-4."""
+    from cellsegmentation_amd.model import resnext as X
+    m = _fill(X.MILresnext50_32x4d(), dev, torch.bfloat16)
+    m.setmode("tile")
+    m.set_encoder_grads(True)
+    m.train()
+    x = synth.normalise(synth.ihc_tiles(8, 128, 31)).to(dev)
+    y = torch.tensor([i % 2 for i in range(8)], device=dev)
+    _assert_same(*_twice(m, lambda: HF.cross_entropy(m(x, freeze_bn=True), y)))
+
+
+def test_loss_values_of_many_workgroups_repeat_and_are_exact(dev):
+    """The VALUE of a CE / MSE launch with more than one workgroup (the logged per-pixel CE of train/train.py:186: ~700 k rows) is the
+    exactly accumulated sum of the workgroups' partial sums: equal across runs, and within fp32 rounding of an fp64 reference."""
+    from cellsegmentation_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    M = 300_007
+    logits = (torch.randn((M, 2), generator=g) * 3).to(dev)
+    labels = torch.randint(0, 2, (M,), generator=g).to(dev)
+    a, _ = K.softmax_ce(logits, labels, 1.0, want_grad=False)
+    b, _ = K.softmax_ce(logits, labels, 1.0, want_grad=False)
+    ref = torch.nn.functional.cross_entropy(logits.double(), labels)
+    x, t = torch.randn((M,), generator=g).to(dev), (torch.rand((M,), generator=g) * 40).to(dev)
+    c, _ = K.mse(x, t, weighted=True, mean=True, want_grad=False)
+    d, _ = K.mse(x, t, weighted=True, mean=True, want_grad=False)
+    w = torch.where(t >= 20, torch.log(t.double()), t.double())
+    ref2 = (w * (x.double() - t.double()) ** 2).mean()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(c, d)
+    assert abs(float(a) - float(ref)) <= 2e-6 * abs(float(ref)) and abs(float(c) - float(ref2)) <= 2e-6 * abs(float(ref2))
