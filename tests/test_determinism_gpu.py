@@ -105,8 +105,7 @@ def test_c5_segmentation_step_repeats_bit_for_bit(arch, n, size, dev):
 def test_resnext50_tile_step_repeats_bit_for_bit(dev):
     """Grouped 3x3 convolutions (model/resnext.py:76-91): float column sums of the grouped data gradients and the per-row dot products
     of the stand-alone finalize were atomic sums in rounds 1-4."""
-    from cellsegmentation_amd.model import resnext as X
-    m = _fill(X.MILresnext50_32x4d(), dev, torch.bfloat16)
+    m = _fill(R.MILresnext50_32x4d(), dev, torch.bfloat16)
     m.setmode("tile")
     m.set_encoder_grads(True)
     m.train()
