@@ -539,6 +539,9 @@ _grad_sink = None
 # batched weight gradients on a second HIP stream, concurrently with the dgrad chain: measured 2 % SLOWER on the ResNet-50 tile step
 # (6395 vs 6522 tiles/s: the groups complete late and then compete with the HBM-bound dgrads of the next stage), so opt-in only
 WGRAD_SIDE_STREAM = os.environ.get("CELLSEG_WGRAD_STREAM", "0") == "1"
+# ... or only the groups of the deep stages (destination pixels <= this many: their weight gradients AND the data gradients they would run
+# beside are launches of <= 256 workgroups that leave most of the chip idle); 0 = off.  Round 5 A/B inside the captured step.
+WGRAD_SIDE_MAX_M = int(os.environ.get("CELLSEG_WGRAD_STREAM_MAX_M", "0") or 0)
 _side_streams = {}
 
 
@@ -581,7 +584,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
     arena = torch.zeros((arena_elems,), dtype=torch.float32, device=dev_) if (arena_elems and dev_ is not None) else None
     arena_pos = [0]
     main = torch.cuda.current_stream() if (dev_ is not None and dev_.type == "cuda") else None
-    side = _side_stream(dev_) if (main is not None and WGRAD_SIDE_STREAM) else None
+    side = _side_stream(dev_) if (main is not None and (WGRAD_SIDE_STREAM or WGRAD_SIDE_MAX_M > 0)) else None
     if side is not None and arena is not None:
         arena.record_stream(side)
 
@@ -630,6 +633,10 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
         # Weight gradients are off the critical path (the dgrad chain): optionally on a side stream (WGRAD_SIDE_STREAM)
         if side is None:
             return flush_on_current(items)
+        if not WGRAD_SIDE_STREAM:
+            g_ = items[0].a.geom
+            if g_.N * g_.P * g_.Q > WGRAD_SIDE_MAX_M:
+                return flush_on_current(items)
         for it in items:
             for t_ in (it.x, it.dz, it.a.xp, it.a.st.scale, it.a.st.rstd, getattr(it.gsum, "buf", it.gsum)):
                 if t_ is not None:

@@ -167,7 +167,7 @@ class GradReducer:
             return grad
         if grad is not view and grad.data_ptr() != vptr:
             view.copy_(grad)
-        if _engine.WGRAD_SIDE_STREAM and view.is_cuda:
+        if (_engine.WGRAD_SIDE_STREAM or _engine.WGRAD_SIDE_MAX_M > 0) and view.is_cuda:
             b.streams.add(torch.cuda.current_stream())      # (opt-in engine mode: weight gradients finished on a side stream)
         self._delivered.add(id(param))
         b.pending -= 1
