@@ -77,7 +77,7 @@ _SIGNATURES = {
     "cs_colsum": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_colsum_partial_rows": (c_int, [c_longlong]),
     "cs_colsum_partial": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
-    "cs_positive_bits": (c_int, [_P, c_int, c_longlong, _P, _P]),
+    "cs_positive_bits": (c_int, [_P, c_int, c_longlong, c_int, _P, _P]),
     "cs_adam_chunk_elems": (c_int, []),
     "cs_adam_max_tensors": (c_int, []),
     "cs_adam_step": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_double, c_double, c_double, c_double, c_double, c_double, _P]),

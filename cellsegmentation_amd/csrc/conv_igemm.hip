@@ -34,10 +34,12 @@ struct IgemmParams {
     const float* shift;
     const void* residual;
     const void* mask;
-    // one bit per stored element instead of a 16-bit mask operand: bits_out[(m*NOUT + c) / 8] = which of the 8 outputs of a
-    // chunk are > 0 (written next to a ReLU output); bits_in plays the role of `mask` in a data gradient (1 byte per 16)
+    // one bit per stored element instead of a 16-bit mask operand, CHANNEL-BLOCK-MAJOR (round 5; conv_v2.hip TileOffs): byte
+    // ((c / 32) * bits_M + pixel) * 4 + (c / 8) % 4 holds which of the 8 outputs c .. c + 7 of that pixel are > 0 (written next to a ReLU
+    // output); bits_in plays the role of `mask` in a data gradient (1 byte per 16).  bits_M = pixels of the whole destination tensor.
     unsigned char* bits_out;
     const unsigned char* bits_in;
+    long long bits_M;
     float* slab;      // nullable fp32 [M tiles][2][NOUT]: per-workgroup column sums / sums of squares of the
                       // stored output (no atomics; cs_slab_reduce folds the rows afterwards)
     double* stat_atomic;   // with slab != NULL: add the workgroup's sums to this fp64 [2][NOUT] instead of storing its partial row (launches
@@ -147,7 +149,7 @@ __device__ __forceinline__ void epi_prefetch(const IgemmParams& p, long long m0,
             const long long off = m * p.NOUT + o;          // identity row -> pixel mapping only (dst_step == 1)
             e.res[half * ITERS + it] = (res && ok) ? *reinterpret_cast<const uint4*>(res + off) : make_uint4(0, 0, 0, 0);
             e.msk[half * ITERS + it] = (msk && ok) ? *reinterpret_cast<const uint4*>(msk + off) : make_uint4(0, 0, 0, 0);
-            e.mbits[half * ITERS + it] = (p.bits_in && ok) ? (unsigned)p.bits_in[off >> 3] : 0u;
+            e.mbits[half * ITERS + it] = (p.bits_in && ok) ? (unsigned)p.bits_in[((long long)(o >> 5) * p.bits_M + m) * 4 + ((o >> 3) & 3)] : 0u;
         }
 }
 
@@ -220,13 +222,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
                 v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
                 long long off = off0 + it * off_step;
+                long long pix = m;                       // destination pixel (row-major over the whole tensor): the bit planes' index
                 if (p.dst_step != 1) {
                     const long long img = m / ((long long)p.DH * p.DW);
                     const int rem = (int)(m - img * (long long)p.DH * p.DW);
                     const int a = rem / p.DW;
                     const int b = rem - a * p.DW;
-                    off = ((img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox) * p.NOUT + o;
+                    pix = (img * p.DHF + (long long)a * p.dst_step + p.dst_oy) * p.DWF + (long long)b * p.dst_step + p.dst_ox;
+                    off = pix * p.NOUT + o;
                 }
+                const long long boff = ((long long)(o >> 5) * p.bits_M + pix) * 4 + ((o >> 3) & 3);     // this thread's byte of a bit plane
                 if (p.scale) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
@@ -251,7 +256,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 if (p.bits_in) {
                     unsigned mb;
                     if constexpr (PF) mb = pf->mbits[half * ITERS + it];
-                    else mb = p.bits_in[off >> 3];
+                    else mb = p.bits_in[boff];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
                 } else if (msk) {
@@ -288,7 +293,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     // (DPP row shifts: lane i takes lane i+1 / i+2 of its 16-lane row; a ds_bpermute shuffle costs an LDS round trip)
                     mb |= (unsigned)__builtin_amdgcn_mov_dpp((int)mb, 0x101, 0xf, 0xf, true) << 8;      // row_shl:1
                     mb |= (unsigned)__builtin_amdgcn_mov_dpp((int)mb, 0x102, 0xf, 0xf, true) << 16;     // row_shl:2
-                    if ((tid & 3) == 0) *reinterpret_cast<unsigned*>(p.bits_out + (off >> 3)) = mb;
+                    if ((tid & 3) == 0) *reinterpret_cast<unsigned*>(p.bits_out + boff) = mb;
                 }
                 if (p.slab) {
 #pragma unroll
@@ -1196,6 +1201,7 @@ static int conv2d_fwd_impl(const CsConvGeom* g, int dtype, const void* x, const 
     p.scale = scale; p.shift = shift; p.residual = residual; p.mask = nullptr;
     CS_CHECK_ARG(!relu_bits || g->K % 32 == 0, "conv2d_fwd_bits: stored output channels must be a multiple of 32");
     p.bits_out = relu_bits; p.bits_in = nullptr;
+    p.bits_M = (long long)g->N * g->P * g->Q;
     p.slab = stats ? reinterpret_cast<float*>(workspace) : nullptr;
     p.SH = g->H; p.SW = g->W; p.SC = g->C;
     p.DH = g->P; p.DW = g->Q; p.NOUT = g->K;
@@ -1215,11 +1221,37 @@ static int conv2d_fwd_impl(const CsConvGeom* g, int dtype, const void* x, const 
     return dtype == CS_F32 ? dispatch_igemm<float>(p, nullptr, stats, st) : dispatch_igemm<bf16_t>(p, nullptr, stats, st);
 }
 
+// can the (up to) four parity classes of a stride-2 data gradient go out as ONE launch (conv2d_dgrad_impl)?  Then its partial column-sum
+// rows are numbered across the classes (IgemmParams::ClassOv::row0) and may be left unfolded like a stride-1 launch's.
+static bool strided_classes_merge(const CsConvGeom* g, int slab) {
+    if (g->stride != 2 || g->R * g->S > 64 || slab || g_igemm_path != 0 || !g_merge_classes) return false;
+    const unsigned long long sbytes = (unsigned long long)g->N * g->P * g->Q * g->K * 4ull;      // (fp32: the larger of the two dtypes)
+    const unsigned long long wbytes = (unsigned long long)g->C * g->R * g->S * (unsigned long long)g->K * 4ull;
+    return sbytes < 0x80000000ull && wbytes < 0x80000000ull;
+}
+
 extern "C" int cs_conv2d_dgrad_partial_rows(const CsConvGeom* g) {
     if (!g) return 0;
-    const long long M = (long long)g->N * g->H * g->W;
-    const int bm = igemm_tile(M, g->C) / 1000;
-    return (int)((M + bm - 1) / bm);
+    if (g->stride == 1) {
+        const long long M = (long long)g->N * g->H * g->W;
+        const int bm = igemm_tile(M, g->C) / 1000;
+        return (int)((M + bm - 1) / bm);
+    }
+    if (g->groups > 1 || !strided_classes_merge(g, 0)) return 0;          // not deferrable: the caller passes a `colsum` target
+    long long max_m = 0, ms[4];
+    int n = 0;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int dh = (g->H - py + 1) / 2, dw = (g->W - px + 1) / 2;
+            if (dh <= 0 || dw <= 0) continue;
+            ms[n] = (long long)g->N * dh * dw;
+            if (ms[n] > max_m) max_m = ms[n];
+            ++n;
+        }
+    const int bm = igemm_tile(max_m, g->C) / 1000;
+    long long rows = 0;
+    for (int i = 0; i < n; ++i) rows += (ms[i] + bm - 1) / bm;
+    return (int)rows;
 }
 
 extern "C" int cs_fold_partial_rows(const float* partial, int rows, int n_out, float* out, void* stream) {
@@ -1260,8 +1292,12 @@ static int conv2d_dgrad_impl(const CsConvGeom* g, int dtype, const void* dy, con
     p.src = dy; p.wgt = w_chwk; p.dst = dx;
     p.scale = nullptr; p.shift = nullptr; p.residual = add; p.mask = mask;
     p.bits_out = nullptr; p.bits_in = mask_bits;
+    p.bits_M = (long long)g->N * g->H * g->W;
+    CS_CHECK_ARG(!mask_bits || g->C % 32 == 0, "conv2d_dgrad_bits: stored input channels must be a multiple of 32");
     const bool deferred = !colsum && workspace;
-    CS_CHECK_ARG(!deferred || (g->stride == 1 && !slab), "conv2d_dgrad: deferred column sums need a stride-1, ungrouped launch");
+    CS_CHECK_ARG(!deferred || (!slab && (g->stride == 1 || strided_classes_merge(g, slab))),
+                 "conv2d_dgrad: deferred column sums need an ungrouped launch of stride 1, or of stride 2 whose parity classes merge "
+                 "(cs_conv2d_dgrad_partial_rows > 0)");
     p.slab = (colsum || deferred) ? reinterpret_cast<float*>(workspace) : nullptr;
     p.SH = g->P; p.SW = g->Q; p.SC = g->K;
     p.DH = g->H; p.DW = g->W; p.NOUT = g->C;

@@ -318,8 +318,11 @@ struct TileOffs {
     static constexpr bool kPreset = false;
     static constexpr unsigned NONE = 0x7fffff00u;      // M < 2^31 - 512: NONE + 16 * 7 neither wraps nor passes the test
     unsigned rb, mr, bb, br;
-    // `piece`: which 16 bytes of the wave's 64 this lane handles; bits: lanes with (lane & 3) == q hold the dword of pixel q
-    __device__ __forceinline__ void set(unsigned base, bool ok, unsigned nout, unsigned n_w, unsigned piece) {
+    // `piece`: which 16 bytes of the wave's 64 this lane handles; bits: lanes with (lane & 3) == q hold the dword of pixel q.
+    // Bit planes are CHANNEL-BLOCK-MAJOR (round 5): dword (n_w / 32) * M + m holds the 32 channels [n_w, n_w + 32) of pixel m, so the 32
+    // dwords a wave stores (loads) for a 32-pixel tile are 128 contiguous bytes.  In the pixel-major layout of rounds 1-4 they were
+    // 32 dwords NOUT / 8 bytes apart: 32 sectors per instruction, 3-4 % of every forward launch that writes a plane (round 4 notes).
+    __device__ __forceinline__ void set(unsigned base, bool ok, unsigned nout, unsigned n_w, unsigned piece, unsigned M) {
         const unsigned lane = threadIdx.x & 63;
         const bool live = ok && base != 0xffffffffu;
         const unsigned m = base + (lane >> 2);
@@ -327,14 +330,14 @@ struct TileOffs {
         rb = (m * nout + n_w + 8u * piece) * 2u;
         const unsigned mbit = m + 16u * (lane & 1u);
         br = (live && !(lane & 2u)) ? mbit : NONE;
-        bb = (mbit * nout + n_w) >> 3;
+        bb = ((n_w >> 5) * M + mbit) * 4u;
     }
     __device__ __forceinline__ unsigned row(unsigned M, unsigned nout, int i, int q) const {
         const unsigned d = (unsigned)(2 * i + q);
         return mr + 16u * d < M ? rb + d * (32u * nout) : OOB;
     }
     __device__ __forceinline__ unsigned bit(unsigned M, unsigned nout, int i) const {
-        return br + 32u * (unsigned)i < M ? bb + (unsigned)i * (4u * nout) : OOB;
+        return br + 32u * (unsigned)i < M ? bb + (unsigned)i * 128u : OOB;
     }
 };
 // The same offsets for a 2-D pixel tile (wide images, round 3): local pixel j of the tile is (y0 + (j >> TWl), x0 + (j & (TW - 1))); every
@@ -343,7 +346,7 @@ template <int TM> struct TileOffs2D {
     static constexpr bool kPreset = true;
     unsigned ro[TM][2], bo[TM];
     __device__ __forceinline__ void set2d(unsigned n, unsigned y0, unsigned x0, unsigned dh, unsigned dw, unsigned twl, unsigned j0, bool alive,
-                                          unsigned nout, unsigned n_w, unsigned piece) {
+                                          unsigned nout, unsigned n_w, unsigned piece, unsigned M) {
         const unsigned lane = threadIdx.x & 63, tw1 = (1u << twl) - 1u;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -357,7 +360,7 @@ template <int TM> struct TileOffs2D {
             const unsigned jb = j0 + 32u * i + (lane >> 2) + 16u * (lane & 1u);
             const unsigned yb = y0 + (jb >> twl), xb = x0 + (jb & tw1);
             const unsigned mb = (n * dh + yb) * dw + xb;
-            bo[i] = (alive && !(lane & 2u) && yb < dh && xb < dw) ? (mb * nout + n_w) >> 3 : OOB;
+            bo[i] = (alive && !(lane & 2u) && yb < dh && xb < dw) ? ((n_w >> 5) * M + mb) * 4u : OOB;       // channel-block-major plane
         }
     }
     __device__ __forceinline__ unsigned row(unsigned, unsigned, int i, int q) const { return ro[i][q]; }
@@ -429,7 +432,7 @@ template <int TM, bool PRE_RES, bool DG, typename TO = TileOffs> struct Epilogue
         const int lane = threadIdx.x & 63;
         const int hh = lane >> 5;
         const unsigned out_bytes = p.M * (unsigned)p.NOUT * 2u;
-        if constexpr (!TO::kPreset) to.set(m0w, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
+        if constexpr (!TO::kPreset) to.set(m0w, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3), p.M);
         r_dst = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, out_bytes, 0x00020000);
         r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0,
                                                   !p.residual ? 0u : p.add_stride == 2 ? (unsigned)(p.NS * p.AH * p.AW * p.NOUT) * 2u : out_bytes, 0x00020000);
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(50))) void c
             const unsigned pix = (n * (unsigned)p.SH + (unsigned)sy) * (unsigned)p.SW + (unsigned)sx;
             voff[j] = real ? pix * p.pix_bytes + (unsigned)(lane >> 4) * 16u : OOB;
         }
-        epi.to.set2d(n, y0, x0, (unsigned)p.DH, (unsigned)p.DW, (unsigned)p.TWl, j0, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3));
+        epi.to.set2d(n, y0, x0, (unsigned)p.DH, (unsigned)p.DW, (unsigned)p.TWl, j0, alive, (unsigned)p.NOUT, (unsigned)n_w, (unsigned)(lane & 3), p.M);
     } else {
         auto pos0 = [&](unsigned m) -> unsigned {      // padded-linear position of tap offset (0,0) of destination pixel m
             const unsigned yall = udivm(m, p.mg_dw, p.sh_dw);
@@ -1076,8 +1079,8 @@ template <int TM, bool DG> struct RingEpilogue {
     TileOffs cur, nxt;         // offsets of the pixel tile being finished / of the one whose operands are being armed
     __device__ __forceinline__ void set_tile(unsigned base, unsigned base_next) {
         m0w = base; m0w_next = base_next;
-        cur.set(base, alive, (unsigned)p.NOUT, (unsigned)n_w, piece());
-        nxt.set(base_next, alive, (unsigned)p.NOUT, (unsigned)n_w, piece());
+        cur.set(base, alive, (unsigned)p.NOUT, (unsigned)n_w, piece(), p.M);
+        nxt.set(base_next, alive, (unsigned)p.NOUT, (unsigned)n_w, piece(), p.M);
     }
     __device__ __forceinline__ unsigned row_lds(int i, int q) const { return region + (unsigned)i * 2048u + (unsigned)q * 1024u + (threadIdx.x & 63u) * 16u; }
     __device__ __forceinline__ unsigned acc_lds(int i, int j) const {
@@ -1138,7 +1141,7 @@ template <int TM, bool DG> struct RingEpilogue {
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(sh[r]));
         TileOffs first;
-        first.set(first_base, alive, (unsigned)p.NOUT, (unsigned)n_w, piece());
+        first.set(first_base, alive, (unsigned)p.NOUT, (unsigned)n_w, piece(), p.M);
         arm_all(first, std::make_integer_sequence<int, TM>{});
     }
 

@@ -717,15 +717,19 @@ static int colsum_rows_per_block(long long M) {
     return (int)(rows < 64 ? 64 : rows);
 }
 
-// bits[i >> 3] bit (i & 7) = (x[i] > 0) for a bf16 tensor with a multiple of 32 elements: the ReLU-mask bit plane of conv_v2's
-// data-gradient epilogue (one byte per pixel per 8 channels) for tensors no convolution epilogue produced (a train-mode BN + ReLU
-// output, a concatenation of two such tensors).  One lane = 32 elements in, one dword out.
-__global__ __launch_bounds__(256) void positive_bits_kernel(const uint4* __restrict__ x, unsigned* __restrict__ bits, long long n32) {
+// Bit plane of a bf16 NHWC tensor x[M][C] (C a multiple of 32) in the CHANNEL-BLOCK-MAJOR layout of the convolution epilogues: dword
+// (c / 32) * M + m, bit c % 32 = (x[m][c] > 0) -- the ReLU-mask plane of the data-gradient epilogues for tensors no convolution epilogue
+// produced (a train-mode BN + ReLU output, a concatenation of two such tensors).  One lane = 32 channels of one pixel in, one dword out;
+// consecutive lanes take consecutive PIXELS of one channel block: contiguous 256-byte stores, 64-byte reads C * 2 bytes apart.
+__global__ __launch_bounds__(256) void positive_bits_kernel(const uint4* __restrict__ x, unsigned* __restrict__ bits, long long M, int CB) {
+    const long long n32 = M * CB;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n32; i += (long long)gridDim.x * 256) {
+        const long long blk = i / M, m = i - blk * M;
+        const uint4* src = x + (m * CB + blk) * 4;
         unsigned out = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint4 v = x[i * 4 + q];
+            const uint4 v = src[q];
             const unsigned wds[4] = {v.x, v.y, v.z, v.w};
             unsigned b = 0;
 #pragma unroll
@@ -742,14 +746,14 @@ __global__ __launch_bounds__(256) void positive_bits_kernel(const uint4* __restr
     }
 }
 
-extern "C" int cs_positive_bits(const void* x, int dtype, long long n_elems, uint8_t* bits, void* stream) {
-    CS_CHECK_ARG(x && bits && n_elems > 0 && n_elems % 32 == 0, "positive_bits: need a positive multiple of 32 elements");
+extern "C" int cs_positive_bits(const void* x, int dtype, long long n_pixels, int C, uint8_t* bits, void* stream) {
+    CS_CHECK_ARG(x && bits && n_pixels > 0 && C > 0 && C % 32 == 0, "positive_bits: need pixels > 0 and a channel count that is a positive multiple of 32");
     CS_CHECK_ARG(dtype == CS_BF16, "positive_bits: bf16 tensors only (the bit planes belong to the packed bf16 kernels)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long long n32 = n_elems / 32;
+    const long long n32 = n_pixels * (C / 32);
     long long blocks = (n32 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(positive_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)x, (unsigned*)bits, n32);
+    hipLaunchKernelGGL(positive_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)x, (unsigned*)bits, n_pixels, C / 32);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

@@ -452,7 +452,8 @@ def conv_dgrad(geom, dy, w_chwk, add=None, mask=None, colsum=None, grouped=False
     dx = torch.empty((geom.N, geom.H, geom.W, geom.C), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
     geom = _grouped_geom(geom, grouped)
-    defer = defer_colsum and geom.stride == 1 and not grouped
+    # (stride 2: deferrable when the library merges the parity classes into one launch -- it then reports the row count, else 0)
+    defer = defer_colsum and not grouped and (geom.stride == 1 or lib.cs_conv2d_dgrad_partial_rows(ctypes.byref(geom)) > 0)
     ws = _stats_ws(geom.N * geom.H * geom.W, geom.C, dy.device) if (colsum is not None or defer) else None
     if mask_bits is not None:
         _lib.check(_timed("dgrad", geom, dy.dtype, lambda: lib.cs_conv2d_dgrad_bits(
@@ -560,14 +561,34 @@ def colsum(g, out=None):
 
 
 def positive_bits(x):
-    """uint8 [..., C/8] bit plane of a bf16 NHWC tensor: bit (c & 7) of byte c >> 3 = x[..., c] > 0 -- the `mask_bits` operand of the packed
-    data gradients for a post-ReLU tensor that no convolution epilogue produced (train-mode BN + ReLU outputs, their concatenation)."""
+    """Bit plane of a bf16 NHWC tensor: bit = x[..., c] > 0, in the channel-block-major layout of the convolution epilogues (the 32-bit
+    word (c // 32) * M + pixel holds channels 32 (c // 32) .. + 31 of that pixel; unpack_bits / pack_bits translate) -- the `mask_bits`
+    operand of the packed data gradients for a post-ReLU tensor that no convolution epilogue produced (train-mode BN + ReLU outputs,
+    their concatenation).  Returned as uint8 [..., C/8] (a shape carrier: the bytes are NOT in NHWC order)."""
     C = x.shape[-1]
     if x.dtype != torch.bfloat16 or C % 32 or not x.is_contiguous():
         raise ValueError("positive_bits: contiguous bf16 tensor with a channel count that is a multiple of 32")
     bits = torch.empty(x.shape[:-1] + (C // 8,), dtype=torch.uint8, device=x.device)
-    _lib.check(_lib.load().cs_positive_bits(_p(x), _code(x.dtype), x.numel(), _p(bits), _stream()), "positive_bits")
+    _lib.check(_lib.load().cs_positive_bits(_p(x), _code(x.dtype), x.numel() // C, C, _p(bits), _stream()), "positive_bits")
     return bits
+
+
+def unpack_bits(bits, C):
+    """bool [..., C] from a bit plane of the library (uint8, M * C / 8 bytes, channel-block-major: see positive_bits)."""
+    M = bits.numel() * 8 // C
+    words = bits.contiguous().view(-1).view(C // 32, M, 4)                       # [block][pixel][byte of the little-endian word]
+    sh = torch.arange(8, dtype=torch.uint8, device=bits.device)
+    b = ((words.unsqueeze(-1) >> sh) & 1).bool()                                  # [block][pixel][byte][bit]
+    return b.permute(1, 0, 2, 3).reshape(tuple(bits.shape[:-1]) + (C,))
+
+
+def pack_bits(mask):
+    """The inverse: a bool / 0-1 tensor [..., C] (C % 32 == 0) -> uint8 [..., C/8] in the library's bit-plane layout."""
+    C = mask.shape[-1]
+    M = mask.numel() // C
+    b = mask.reshape(M, C // 32, 4, 8).to(torch.uint8)
+    w = (b << torch.arange(8, dtype=torch.uint8, device=mask.device)).sum(-1).to(torch.uint8)       # [pixel][block][byte]
+    return w.permute(1, 0, 2).contiguous().view(tuple(mask.shape[:-1]) + (C // 8,))
 
 
 def colsum_partial(g):

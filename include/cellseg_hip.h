@@ -172,13 +172,18 @@ int cs_set_igemm_path(int path);
 int cs_conv2d_dgrad(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                     const void* mask, void* dx, float* colsum, void* workspace, void* stream);
 /* One bit per element instead of a 16-bit mask operand (the ReLU masks are 1/6 of a training step's HBM traffic otherwise):
- * cs_conv2d_fwd_bits also writes positive_bits[(pixel*K + k) / 8], bit (k % 8) = "the stored y is > 0"; cs_conv2d_dgrad_bits takes
- * such a tensor (shaped like x: N*H*W*C/8 bytes) in place of `mask`. */
+ * cs_conv2d_fwd_bits also writes the plane `positive_bits`: M * K / 8 bytes (M = N*P*Q pixels, K % 32 == 0), CHANNEL-BLOCK-MAJOR since
+ * round 5 (ABI 6): the 32-bit word (k / 32) * M + pixel holds channels 32 (k / 32) .. + 31 of that pixel, bit k % 32 = "the stored y is
+ * > 0" -- a wave's 32 words of a 32-pixel tile are 128 contiguous bytes (the pixel-major layout of rounds 1-4 put them K / 8 bytes apart:
+ * 32 sectors per store instruction).  cs_conv2d_dgrad_bits takes such a plane (of a tensor shaped like x: N*H*W pixels, C channels,
+ * C % 32 == 0) in place of `mask`.  Every producer / consumer of bit planes in this library uses this layout (cs_conv2d_fwd_packed,
+ * cs_stem_fwd_packed, cs_conv2d_dgrad_packed, cs_positive_bits). */
 int cs_conv2d_fwd_bits(const CsConvGeom* g, int dtype, const void* x, const void* w_khwc, const float* scale, const float* shift,
                        const void* residual, int act, void* y, uint8_t* positive_bits, void* stream);
 int cs_conv2d_dgrad_bits(const CsConvGeom* g, int dtype, const void* dy, const void* w_chwk, const void* add,
                          const uint8_t* mask_bits, void* dx, float* colsum, void* workspace, void* stream);
-/* Deferred column sums: with colsum == NULL and workspace != NULL (stride-1, ungrouped launches only) cs_conv2d_dgrad leaves the
+/* Deferred column sums: with colsum == NULL and workspace != NULL (ungrouped launches of stride 1, and of stride 2 where
+ * cs_conv2d_dgrad_partial_rows(g) > 0: the parity classes then go out as one launch with rows numbered across them) cs_conv2d_dgrad leaves the
  * per-workgroup partial rows in `workspace` -- row r holds the sums of destination-pixel tile r at [r * 2*C + c] -- and skips the
  * fold.  cs_conv2d_dgrad_partial_rows gives the row count; cs_fold_partial_rows folds one such buffer (out[c] += sum over rows, in a
  * fixed order: the unused second half of the first <= 32 partial rows serves as scratch, so `partial` is written to);
@@ -264,9 +269,10 @@ int cs_adam_step_dev(const CsAdamTensor* tensors_dev, const void* const* grads_h
 size_t cs_sample_sum_workspace(int N, int HW, int C);
 int cs_sample_sum(const void* a, const void* b, int dtype, float scale, float* out, float* workspace, int N, int HW, int C,
                   void* stream);
-/* bit plane of a bf16 NHWC tensor: bits[i >> 3] bit (i & 7) = x[i] > 0 (the `mask_bits` operand of cs_conv2d_dgrad_packed for a
- * post-ReLU tensor that no convolution epilogue produced, e.g. torch.cat of two ReLU outputs, resnet.py:284-294); n_elems % 32 == 0 */
-int cs_positive_bits(const void* x, int dtype, long long n_elems, uint8_t* bits, void* stream);
+/* bit plane of a bf16 NHWC tensor x[n_pixels][C] in the layout of cs_conv2d_fwd_bits (channel-block-major, below): the `mask_bits`
+ * operand of cs_conv2d_dgrad_packed for a post-ReLU tensor that no convolution epilogue produced, e.g. torch.cat of two ReLU outputs,
+ * resnet.py:284-294; C % 32 == 0 */
+int cs_positive_bits(const void* x, int dtype, long long n_pixels, int C, uint8_t* bits, void* stream);
 int cs_colsum_partial(const void* g, int dtype, long long M, int C, float* partial, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------

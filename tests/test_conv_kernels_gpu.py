@@ -226,9 +226,7 @@ def test_paired_stem_equals_the_generic_7x7_path(dev, dtype, hw):
         y2, bits = K.stem_fwd_packed(g, xp, K.stem_pack_weights(wp), shift, K.CS_ACT_RELU, want_bits=True)
         torch.cuda.synchronize()
         assert float((y2.float() - y_ref.float()).abs().max()) <= tol * max(1.0, float(y_ref.float().abs().max()))
-        sh = torch.arange(8, dtype=torch.uint8, device=dev)
-        got_bits = ((bits.unsqueeze(-1) >> sh) & 1).bool().reshape(N, g.P, g.Q, Kc)
-        assert torch.equal(got_bits, y2 > 0)
+        assert torch.equal(K.unpack_bits(bits, Kc), y2 > 0)
     # batch statistics through the same entry point
     st_ref, st = K.new_stats(Kc, dev), K.new_stats(Kc, dev)
     K.conv_fwd(g, x, wk, None, shift, None, K.CS_ACT_NONE, stats=st_ref)

@@ -69,19 +69,13 @@ def _relerr(a, b):
 
 
 def _unpack_bits(bits, C):
-    """uint8 [N,H,W,C/8] -> bool [N,C,H,W]"""
-    b = bits.cpu()
-    sh = torch.arange(8, dtype=torch.uint8)
-    out = ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(*b.shape[:-1], C)
-    return out.permute(0, 3, 1, 2)
+    """a bit plane of the library (channel-block-major, kernels.unpack_bits) -> bool [N,C,H,W]"""
+    return K.unpack_bits(bits, C).cpu().permute(0, 3, 1, 2)
 
 
 def _pack_bits(mask_nchw, dev):
-    """bool [N,C,H,W] -> uint8 [N,H,W,C/8]"""
-    m = mask_nchw.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
-    m = m.reshape(*m.shape[:-1], m.shape[-1] // 8, 8)
-    w = (m << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8)
-    return w.to(dev)
+    """bool [N,C,H,W] -> a bit plane in the library's layout (kernels.pack_bits)"""
+    return K.pack_bits(mask_nchw.permute(0, 2, 3, 1).contiguous().to(dev))
 
 
 @pytest.mark.parametrize("shape", SHAPES)

@@ -130,14 +130,11 @@ def test_bit_masks_equal_the_tensor_masks(shape, dtype, dev, monkeypatch):
         y_plain = K.conv_fwd(geom, x, w_khwc, None, shift, residual, K.CS_ACT_RELU)
         torch.cuda.synchronize()
         assert torch.equal(y, y_plain), "the bit-writing launch must store the same tensor"
-        sh = torch.arange(8, dtype=torch.uint8, device=dev)
-        unpacked = ((bits.unsqueeze(-1) >> sh) & 1).bool().reshape(N, geom.P, geom.Q, Cout)
-        assert torch.equal(unpacked, y > 0)
+        assert torch.equal(K.unpack_bits(bits, Cout), y > 0)
     # data gradient: mask given as bits == mask given as the activation tensor, bit for bit
     dy = torch.randn((N, geom.P, geom.Q, Cout), generator=g).to(dtype).to(dev)
     act = torch.relu(torch.randn((N, H, W, Cin), generator=g)).to(dtype).to(dev)       # the conv's input, a post-ReLU tensor
-    m8 = (act > 0).reshape(N, H, W, Cin // 8, 8).to(torch.uint8)
-    mask_bits = (m8 << torch.arange(8, dtype=torch.uint8, device=dev)).sum(-1).to(torch.uint8).contiguous()
+    mask_bits = K.pack_bits(act > 0)
     add = torch.randn((N, H, W, Cin), generator=g).to(dtype).to(dev)
     for a in (None, add):
         cs1 = torch.zeros((Cin,), dtype=torch.float32, device=dev)

@@ -257,7 +257,9 @@ def test_tile_gather_matches_get_tiles_totensor_normalize(dev):
 
 
 def test_positive_bits_plane(dev):
-    """cs_positive_bits: bit (c & 7) of byte c >> 3 = x[..., c] > 0 (the mask operand the packed data gradients read)."""
+    """cs_positive_bits in the channel-block-major layout every bit-plane producer / consumer of the library uses: the 32-bit word
+    (c // 32) * M + pixel, bit c % 32 = x[pixel, c] > 0 (the mask operand the packed data gradients read); kernels.unpack_bits /
+    pack_bits are its torch-side inverse pair."""
     torch.manual_seed(9)
     x = torch.randn(3, 5, 7, 96)
     x[x.abs() < 0.3] = 0.0
@@ -265,6 +267,11 @@ def test_positive_bits_plane(dev):
     xb = x.to(torch.bfloat16)
     bits = K.positive_bits(xb.to(dev)).cpu()
     assert bits.shape == (3, 5, 7, 12) and bits.dtype == torch.uint8
-    ref = (xb.float() > 0).view(3, 5, 7, 12, 8)
-    w = (2 ** torch.arange(8)).view(1, 1, 1, 1, 8)
-    assert torch.equal(bits.long(), (ref.long() * w).sum(-1))
+    M = 3 * 5 * 7
+    ref = (xb.float() > 0).view(M, 3, 32)                                  # [pixel][block][bit]
+    words = (ref.long() * (2 ** torch.arange(32)).view(1, 1, 32)).sum(-1).t().contiguous()       # [block][pixel]
+    got = bits.view(-1).view(3, M, 4).long()
+    got_words = got[..., 0] + (got[..., 1] << 8) + (got[..., 2] << 16) + (got[..., 3] << 24)
+    assert torch.equal(got_words, words)
+    assert torch.equal(K.unpack_bits(bits, 96), xb.float() > 0)
+    assert torch.equal(K.pack_bits(xb.float() > 0), bits)
