@@ -204,17 +204,18 @@ __global__ __launch_bounds__(256) void linear_bwd_dual_kernel(const float* __res
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                          float gamma, float* __restrict__ loss, float* __restrict__ dlogits,
                                                          int M, int C) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride over the rows: at most kLossBlocks workgroups contribute to the exact accumulator (its additions are exact for up to
+    // 2^12 contributors, cs_common.h), whatever M is
     float li = 0.f;
-    if (m < M) {
-        const float* r = logits + (long long)m * C;
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+        const float* r = logits + m * C;
         float mx = r[0];
         for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(r[c] - mx);
         const float lse = mx + logf(se);
         const int lab = (int)labels[m];
-        li = (lse - r[lab]) * (gamma / (float)M);
+        li += (lse - r[lab]) * (gamma / (float)M);
         if (dlogits) {
             const float gs = gamma / (float)M;
             for (int c = 0; c < C; ++c) {
@@ -264,13 +265,12 @@ __global__ void softmax_argmax_kernel(const float* __restrict__ logits, long lon
 
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, int weighted,
                                                   float inv, float* __restrict__ loss, float* __restrict__ dx, int M) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
     float li = 0.f;
-    if (m < M) {
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {      // (as softmax_ce_kernel)
         const float d = x[m] - t[m];
         float w = 1.f;
         if (weighted) w = t[m] >= 20.f ? logf(t[m]) : t[m];
-        li = w * d * d * inv;
+        li += w * d * d * inv;
         if (dx) dx[m] = 2.f * w * d * inv;
     }
     __shared__ float red[4];
@@ -437,6 +437,7 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
 
 // floats behind a loss value: [0] the result, [1] unused, [2 .. 15] an exact accumulator of one channel (7 eight-byte words)
 constexpr int kLossWords = 16;
+constexpr int kLossBlocks = 2048;       // workgroups of a loss launch: the exact accumulator takes <= 2^12 contributions
 extern "C" int cs_loss_words(void) { return kLossWords; }
 
 extern "C" int cs_softmax_ce(const float* logits, const int64_t* labels, float gamma, float* loss, float* dlogits, int M, int C,
@@ -444,7 +445,7 @@ extern "C" int cs_softmax_ce(const float* logits, const int64_t* labels, float g
     CS_CHECK_ARG(logits && labels && loss && M > 0 && C > 1, "softmax_ce: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float) * kLossWords, st) != hipSuccess) { cs_set_error_("softmax_ce: memset failed"); return CS_ERR_LAUNCH; }
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, logits, labels, gamma, loss, dlogits, M, C);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((M + 255) / 256 < kLossBlocks ? (M + 255) / 256 : kLossBlocks), dim3(256), 0, st, logits, labels, gamma, loss, dlogits, M, C);
     CS_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, loss);
     CS_LAUNCH_CHECK();
@@ -472,7 +473,7 @@ extern "C" int cs_mse(const float* x, const float* t, int weighted, int mean, fl
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float) * kLossWords, st) != hipSuccess) { cs_set_error_("mse: memset failed"); return CS_ERR_LAUNCH; }
     const float inv = mean ? 1.f / (float)M : 1.f;
-    hipLaunchKernelGGL(mse_kernel, dim3((M + 255) / 256), dim3(256), 0, st, x, t, weighted, inv, loss, dx, M);
+    hipLaunchKernelGGL(mse_kernel, dim3((M + 255) / 256 < kLossBlocks ? (M + 255) / 256 : kLossBlocks), dim3(256), 0, st, x, t, weighted, inv, loss, dx, M);
     CS_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, loss);
     CS_LAUNCH_CHECK();
