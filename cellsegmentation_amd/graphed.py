@@ -62,3 +62,42 @@ class GraphedStep:
         # the replay updated parameters / BN statistics without running host code: cached staged weights are stale now
         engine.invalidate_staged()
         return self.outputs
+
+
+class GraphedGrad:
+    """zero_grad -> forward -> loss -> backward of a training step as one HIP graph; ``optimizer.step()`` stays outside.
+
+    For loops whose optimizer cannot be captured -- the reference's drivers build a plain ``optim.Adam`` whose step counts live on the
+    host (train_tile.py:282) -- the ~95 % of a step's launches that are NOT the optimizer still replay in one launch
+    (``train.use_graphed_steps``).  ``fn(*tensors)`` returns a tuple of tensors, the first of which is the loss to back-propagate.
+    During the capture every ``.grad`` of ``params`` starts as None, so autograd adopts the gradient buffers the HIP backward
+    wrote -- after the capture ``p.grad`` IS that static buffer, every replay overwrites it, and the caller must NOT call
+    ``optimizer.zero_grad()`` between replays (the parameters that receive no gradient keep ``.grad is None``, as in the eager loop).
+    The constructor runs no step; the first call replays."""
+
+    def __init__(self, params, fn, example_inputs):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedGrad needs a GPU")
+        self.params = [p for p in params if p.requires_grad]
+        self.static_inputs = [t.clone() for t in example_inputs]
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            for p in self.params:
+                p.grad = None
+            self.outputs = tuple(fn(*self.static_inputs))
+            self.outputs[0].backward()
+        self.grads = [p.grad for p in self.params]
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError("GraphedGrad: input shape/dtype differs from the captured one")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for p, g in zip(self.params, self.grads):       # (a zero_grad() between replays is undone, not obeyed: the buffers are the graph's)
+            if p.grad is not g:
+                p.grad = g
+        self.graph.replay()
+        engine.invalidate_staged()
+        return self.outputs

@@ -5,6 +5,9 @@ HIP backward -> optimizer.step.  Two deliberate host-side differences from the r
 changing results: the per-step ``loss.item()`` sync is replaced by an on-device accumulator read once
 per epoch, and ``print`` of ce/dice per step in train_seg is dropped (the CE there is never used).
 """
+import os
+import weakref
+
 import torch
 from torch.optim.lr_scheduler import CyclicLR, OneCycleLR
 
@@ -19,6 +22,67 @@ except ImportError:  # pragma: no cover
 
 def _per_step(scheduler):
     return isinstance(scheduler, (CyclicLR, OneCycleLR))
+
+
+# ---- optional: the loop bodies replay zero_grad -> forward -> loss -> backward as ONE HIP graph (graphed.GraphedGrad); the optimizer
+# and the scheduler the driver passed in stay eager.  Off by default (the reference's semantics, launch by launch); CELLSEG_GRAPH_STEPS=1
+# or train.use_graphed_steps(True) switch it on.  A step is captured once a batch SHAPE has been seen `_WARM` times eagerly (lazily built
+# tables, allocator); other shapes -- the ragged last batch -- keep running eagerly.  The eager launches of the ResNet-18 image counter
+# at batch 8 are host-bound (~500 launches, 4.5 ms of enqueueing for 1.9 ms of GPU work).
+_GRAPH_STEPS = [os.environ.get("CELLSEG_GRAPH_STEPS", "0") == "1"]
+_WARM = 2
+_RUNNERS = weakref.WeakKeyDictionary()       # model -> {key: _Runner}
+
+
+def use_graphed_steps(on=True):
+    """Replay the forward + backward of the train_* loops as HIP graphs (see above).  Returns the previous setting."""
+    prev, _GRAPH_STEPS[0] = _GRAPH_STEPS[0], bool(on)
+    return prev
+
+
+class _Runner:
+    """One loop's step: eager, or (graphed steps on) a GraphedGrad per input signature.  body(*tensors) -> tuple of loss tensors, the
+    first one is back-propagated."""
+
+    def __init__(self, model, optimizer, body):
+        self.model, self.optimizer, self.body = model, optimizer, body
+        self.seen, self.graphs = {}, {}
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+
+    def __call__(self, *tensors):
+        if _GRAPH_STEPS[0] and all(t.is_cuda for t in tensors):
+            key = tuple((tuple(t.shape), t.dtype) for t in tensors)
+            g = self.graphs.get(key)
+            if g is None and self.seen.get(key, 0) >= _WARM and len(self.graphs) < 2:
+                from ..graphed import GraphedGrad
+                g = self.graphs[key] = GraphedGrad(self.params, self.body, tensors)
+            if g is not None:
+                return g(*tensors)
+            self.seen[key] = self.seen.get(key, 0) + 1
+            if self.graphs:
+                # an eager step between replays: the graphs' static gradient buffers must not be accumulated into
+                for p in self.params:
+                    p.grad = None
+        self.optimizer.zero_grad()
+        outs = tuple(self.body(*tensors))
+        outs[0].backward()
+        return outs
+
+
+def _runner(model, optimizer, name, key, body):
+    """The loop's _Runner.  With graphed steps on it is kept on the model across epochs (a capture per epoch would cost more than it
+    saves), keyed by everything the captured body closes over: the loop, the optimizer, the criteria / weights (`key`), the model's mode
+    and which parameters train."""
+    if not _GRAPH_STEPS[0]:
+        return _Runner(model, optimizer, body)
+    full = (name, id(optimizer), key, getattr(model, "mode", None), tuple(p.requires_grad for p in model.parameters()))
+    cache = _RUNNERS.setdefault(model, {})            # (not on the model: train_ensemble.py:202 deep-copies models)
+    r = cache.get(full)
+    if r is None:
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        r = cache[full] = _Runner(model, optimizer, body)
+    return r
 
 
 def _ce(criterion, output, label, gamma=1.0):
@@ -41,11 +105,9 @@ def train_tile(loader, epoch, total_epochs, model, device, criterion, optimizer,
     tile_num = 0
     train_loss = torch.zeros((), device=device)
     train_bar = tqdm(loader, desc="tile training")
+    run = _runner(model, optimizer, "tile", (id(criterion), float(gamma)), lambda x, y: (_ce(criterion, model(x, freeze_bn=True), y, gamma),))
     for i, (data, label) in enumerate(train_bar):
-        optimizer.zero_grad()
-        output = model(data.to(device), freeze_bn=True)
-        loss = _ce(criterion, output, label.to(device), gamma)
-        loss.backward()
+        loss, = run(data.to(device), label.to(device))           # zero_grad -> forward -> loss -> backward (train/train.py:32-35)
         optimizer.step()
         if _per_step(scheduler):
             scheduler.step()
@@ -60,13 +122,15 @@ def train_image(loader, epoch, total_epochs, model, device, crit_cls, crit_reg, 
     """Image-level classification + count regression for one epoch (train/train.py:51-105)."""
     model.train()
     acc = torch.zeros((3,), device=device)
+
+    def body(x, yc, yn):
+        output = model(x)
+        l_cls = _ce(crit_cls, output[0], yc)
+        l_reg = _mse(crit_reg, output[1].squeeze(), yn)
+        return alpha * l_cls + beta * l_reg, l_cls, l_reg
+    run = _runner(model, optimizer, "image", (id(crit_cls), id(crit_reg), float(alpha), float(beta)), body)
     for i, (data, label_cls, label_num) in enumerate(tqdm(loader, desc="image training")):
-        optimizer.zero_grad()
-        output = model(data.to(device))
-        l_cls = _ce(crit_cls, output[0], label_cls.to(device))
-        l_reg = _mse(crit_reg, output[1].squeeze(), label_num.to(device, dtype=torch.float32))
-        loss = alpha * l_cls + beta * l_reg
-        loss.backward()
+        loss, l_cls, l_reg = run(data.to(device), label_cls.to(device), label_num.to(device, dtype=torch.float32))
         optimizer.step()
         if _per_step(scheduler):
             scheduler.step()
@@ -82,11 +146,9 @@ def train_image_cls(loader, epoch, total_epochs, model, device, crit_cls, optimi
     """train/train.py:109-137"""
     model.train()
     acc = torch.zeros((), device=device)
+    run = _runner(model, optimizer, "image_cls", (id(crit_cls),), lambda x, yc: (_ce(crit_cls, model(x)[0], yc),))
     for i, (data, label_cls, label_num) in enumerate(tqdm(loader, desc="image training")):
-        optimizer.zero_grad()
-        output = model(data.to(device))
-        l_cls = _ce(crit_cls, output[0], label_cls.to(device))
-        l_cls.backward()
+        l_cls, = run(data.to(device), label_cls.to(device))
         optimizer.step()
         if _per_step(scheduler):
             scheduler.step()
@@ -100,11 +162,9 @@ def train_image_reg(loader, epoch, total_epochs, model, device, crit_reg, optimi
     """train/train.py:140-169"""
     model.train()
     acc = torch.zeros((), device=device)
+    run = _runner(model, optimizer, "image_reg", (id(crit_reg),), lambda x, yn: (_mse(crit_reg, model(x)[1].squeeze(), yn),))
     for i, (data, label_cls, label_num) in enumerate(tqdm(loader, desc="image training")):
-        optimizer.zero_grad()
-        output = model(data.to(device))
-        l_reg = _mse(crit_reg, output[1].squeeze(), label_num.to(device, dtype=torch.float32))
-        l_reg.backward()
+        l_reg, = run(data.to(device), label_num.to(device, dtype=torch.float32))
         optimizer.step()
         if _per_step(scheduler):
             scheduler.step()
@@ -118,12 +178,10 @@ def train_seg(loader, epoch, total_epochs, model, device, optimizer, scheduler):
     """Segmentation training for one epoch (train/train.py:172-207): loss = Dice(softmax(out)[:,1], mask/255)."""
     model.train()
     acc = torch.zeros((), device=device)
+    run = _runner(model, optimizer, "seg", (), lambda x, m: (HF.dice_loss(HF.softmax_channel(model(x).to(dtype=torch.float32), 1), m),))
     for i, (image, mask, label) in enumerate(tqdm(loader, desc="segmentation training")):
         mask = (mask / 255).to(device, dtype=torch.float32)
-        optimizer.zero_grad()
-        output = model(image.to(device)).to(dtype=torch.float32)
-        loss = HF.dice_loss(HF.softmax_channel(output, 1), mask)
-        loss.backward()
+        loss, = run(image.to(device), mask)
         optimizer.step()
         if _per_step(scheduler):
             scheduler.step()

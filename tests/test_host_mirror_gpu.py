@@ -361,3 +361,61 @@ def test_mixed_frozen_and_train_mode_batchnorm_trains(dev):
         assert torch.isfinite(a).all()
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.98, (k, cos)
+
+
+@pytest.mark.parametrize("loop", ["image", "tile", "seg"])
+def test_graphed_train_loops_equal_the_eager_loops_bit_for_bit(loop, dev):
+    """train.use_graphed_steps(True): the loops of train/train.py replay zero_grad -> forward -> loss -> backward as one HIP graph once a
+    batch shape has been seen twice, the driver's own (non-capturable) optimizer steps eagerly in between, the ragged last batch runs
+    eagerly: per-epoch losses, parameters and BN buffers must equal the all-eager loops BIT FOR BIT over two epochs."""
+    arch = "resnet18"
+    g = torch.Generator().manual_seed(5)
+    if loop == "seg":
+        full, ragged, size = 2, 1, 64
+    else:
+        full, ragged, size = 4, 3, 64
+    sizes = [full] * 5 + [ragged]
+    batches = []
+    for i, n in enumerate(sizes):
+        x = synth.normalise(synth.ihc_tiles(n, size, 300 + i))
+        if loop == "image":
+            counts = torch.randint(0, 60, (n,), generator=g)
+            batches.append((x, torch.tensor([orc.categorize(int(c)) for c in counts]), counts))
+        elif loop == "tile":
+            batches.append((x, torch.randint(0, 2, (n,), generator=g)))
+        else:
+            batches.append((x, (torch.rand(n, size, size, generator=g) > 0.7).to(torch.uint8) * 255, torch.zeros(n)))
+    total = sum(sizes)
+
+    def run(graphed):
+        m = _model(arch, dev)
+        m.setmode({"image": "image", "tile": "tile", "seg": "segment"}[loop])
+        if loop == "tile":
+            m.set_encoder_grads(True)
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        prev = T.use_graphed_steps(graphed)
+        out = []
+        try:
+            for epoch in range(2):
+                ld = _Loader(batches, total, full)
+                if loop == "image":
+                    out.append(T.train_image(ld, epoch, 2, m, dev, torch.nn.CrossEntropyLoss(), torch.nn.MSELoss(), opt, None, 1.0, 0.5))
+                elif loop == "tile":
+                    out.append(T.train_tile(ld, epoch, 2, m, dev, torch.nn.CrossEntropyLoss(), opt, None, 1.0))
+                else:
+                    out.append(T.train_seg(ld, epoch, 2, m, dev, opt, None))
+        finally:
+            T.use_graphed_steps(prev)
+        torch.cuda.synchronize()
+        return out, {k: v.clone() for k, v in m.state_dict().items()}, m
+
+    eager_out, eager_sd, _ = run(False)
+    graph_out, graph_sd, gm = run(True)
+    assert eager_out == graph_out, (eager_out, graph_out)
+    for k in eager_sd:
+        assert torch.equal(eager_sd[k], graph_sd[k]), k
+    from cellsegmentation_amd.train import train as TT
+    runners = TT._RUNNERS.get(gm)
+    assert runners and any(r.graphs for r in runners.values())         # a graph was captured and replayed (not a silent eager run)
+    import copy
+    copy.deepcopy(gm)                                                  # train_ensemble.py:202 deep-copies models: the graphs are not on the model
