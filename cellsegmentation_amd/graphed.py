@@ -73,7 +73,9 @@ class GraphedGrad:
     During the capture every ``.grad`` of ``params`` starts as None, so autograd adopts the gradient buffers the HIP backward
     wrote -- after the capture ``p.grad`` IS that static buffer, every replay overwrites it, and the caller must NOT call
     ``optimizer.zero_grad()`` between replays (the parameters that receive no gradient keep ``.grad is None``, as in the eager loop).
-    The constructor runs no step; the first call replays."""
+    The constructor runs no step; the first call replays.  No autograd graph of an EARLIER eager step may be alive at construction (a
+    loss tensor with a grad_fn kept in a variable is enough): its AccumulateGrad nodes belong to the default stream, which cannot join a
+    capture."""
 
     def __init__(self, params, fn, example_inputs):
         if not torch.cuda.is_available():
@@ -85,8 +87,10 @@ class GraphedGrad:
         with torch.cuda.graph(self.graph):
             for p in self.params:
                 p.grad = None
-            self.outputs = tuple(fn(*self.static_inputs))
-            self.outputs[0].backward()
+            outs = tuple(fn(*self.static_inputs))
+            outs[0].backward()
+            self.outputs = tuple(o.detach() for o in outs)       # (no autograd graph is kept: see train._Runner)
+        del outs
         self.grads = [p.grad for p in self.params]
 
     def __call__(self, *inputs):

@@ -30,7 +30,7 @@ def _per_step(scheduler):
 # tables, allocator); other shapes -- the ragged last batch -- keep running eagerly.  The eager launches of the ResNet-18 image counter
 # at batch 8 are host-bound (~500 launches, 4.5 ms of enqueueing for 1.9 ms of GPU work).
 _GRAPH_STEPS = [os.environ.get("CELLSEG_GRAPH_STEPS", "0") == "1"]
-_WARM = 2
+_WARM = int(os.environ.get("CELLSEG_GRAPH_WARM", "2") or 2)
 _RUNNERS = weakref.WeakKeyDictionary()       # model -> {key: _Runner}
 
 
@@ -66,7 +66,11 @@ class _Runner:
         self.optimizer.zero_grad()
         outs = tuple(self.body(*tensors))
         outs[0].backward()
-        return outs
+        # detached: a loss tensor the loop keeps until its next iteration would keep this step's autograd graph alive -- and with it the
+        # AccumulateGrad nodes of the parameters, which remember the stream they were created on (the default stream here).  A capture
+        # starting while they live re-uses them, autograd then synchronises the capture stream with the legacy default stream, and
+        # hipStreamEndCapture crashes (seen: segmentation fault in capture_end).
+        return tuple(o.detach() for o in outs)
 
 
 def _runner(model, optimizer, name, key, body):
