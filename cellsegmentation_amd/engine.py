@@ -25,6 +25,7 @@ from types import SimpleNamespace
 
 import torch
 
+from . import _capture
 from . import kernels as K
 
 ACT_NONE, ACT_RELU, ACT_SILU = K.CS_ACT_NONE, K.CS_ACT_RELU, K.CS_ACT_SILU
@@ -318,15 +319,23 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
 
     # Training passes re-stage every folded Conv+BN after each optimizer update: one launch for the whole plan (the first such
     # pass stages layer by layer and records the layout; see kernels.StagePack)
+    # (one pack per (dtype, input shape): which layers take packed operands depends on the geometry, and a ragged last batch must not
+    # evict the pack of the full batches -- a captured step keeps replaying into it)
     packs = plan.__dict__.setdefault("_stage_packs", {})
-    pack = packs.get(dtype) if save else None
+    pack_key = (dtype, tuple(t[plan.inputs[0]].shape))
+    pack = packs.get(pack_key) if save else None
     prestaged, record = {}, None
+    capturing = _capture.capturing()
     if save:
         if pack is not None and pack.valid():
             pack.launch()
             prestaged = pack.by_unit
+            if capturing:
+                _capture.keep(pack)
         else:
-            packs.pop(dtype, None)
+            packs.pop(pack_key, None)
+            while len(packs) >= 4:
+                packs.pop(next(iter(packs)))
             record = []
 
     # train-mode BN bookkeeping for the whole plan in two launches instead of two per layer: one zero-filled fp64 arena for the
@@ -373,8 +382,10 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
                 st = pre[1]
             else:
                 if pre is not None:
-                    packs.pop(dtype, None)          # the layout changed (other requires_grad pattern / geometry): rebuild next time
+                    packs.pop(pack_key, None)       # the layout changed (other requires_grad pattern): rebuild next time
                 st = _stage_weights(u, dtype, Cp, Kp, need_bwd, folded=not batch_stats, training=save, geom=geom, pkf=pkf, pkb=pkb)
+                if capturing:
+                    _capture.keep(st)               # (a cached staged set may be replaced by a later eager pass: the graph keeps this one)
                 # (a batch-statistics layer joins the one-launch staging with bn = None: its operands depend on the convolution only)
                 if (record is not None and not u.grouped and (batch_stats or u.bn is not None)
                         and any(p_ is not None and p_.requires_grad
@@ -492,7 +503,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
             pk.by_unit[ui_] = ((cp_, kp_, nb_, pkf_, pkb_, bn_ is None),
                                SimpleNamespace(w_khwc=w_khwc, w_chwk=w_chwk, scale=scale, shift=shift, rstd=rstd,
                                                fwd_packed=bool(pkf_), bwd_packed=bool(pkb_ and nb_)))
-        packs[dtype] = pk
+        packs[pack_key] = pk
     return SimpleNamespace(t=t, aux=aux, in_hw=in_hw, bits=bits)
 
 

@@ -18,7 +18,7 @@ with eager steps in tests/test_graphed_gpu.py): 6.0 ms of host work per step lea
 """
 import torch
 
-from . import engine
+from . import _capture, engine
 
 
 class GraphedStep:
@@ -45,8 +45,10 @@ class GraphedStep:
         for hook in self.pre_replay:
             hook()
         self.graph = torch.cuda.CUDAGraph()
+        _capture.take()
         with torch.cuda.graph(self.graph):
             self.outputs = step_fn(*self.static_inputs)
+        self._refs = _capture.take()        # cached library objects the captured launches point into (see _capture.py)
 
     def __call__(self, *inputs):
         if len(inputs) != len(self.static_inputs):
@@ -84,6 +86,7 @@ class GraphedGrad:
         self.static_inputs = [t.clone() for t in example_inputs]
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        _capture.take()
         with torch.cuda.graph(self.graph):
             for p in self.params:
                 p.grad = None
@@ -91,6 +94,7 @@ class GraphedGrad:
             outs[0].backward()
             self.outputs = tuple(o.detach() for o in outs)       # (no autograd graph is kept: see train._Runner)
         del outs
+        self._refs = _capture.take()
         self.grads = [p.grad for p in self.params]
 
     def __call__(self, *inputs):

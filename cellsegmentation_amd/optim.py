@@ -19,7 +19,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _capture, _lib
 
 
 class Adam(torch.optim.Optimizer):
@@ -174,8 +174,11 @@ class Adam(torch.optim.Optimizer):
             stream = torch.cuda.current_stream(plist[0].device).cuda_stream
             if capt:
                 self.sync_hyper()
-                table, launches, (steps, coef) = self._plan(gi, plist, None)
+                plan = self._plan(gi, plist, None)
+                table, launches, (steps, coef) = plan
                 lr_dev = self._lr_dev[gi][0]
+                if capturing:
+                    _capture.keep((plan, lr_dev))            # the plan cache is LRU: a captured launch keeps its tables alive itself
                 for t0, members, chunks, n_chunks in launches:
                     n = len(members)
                     gts = [plist[i].grad if plist[i].grad.is_contiguous() else plist[i].grad.contiguous() for i in members]
