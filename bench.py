@@ -376,7 +376,7 @@ def secondary_configs(timeout_s=240):
     Never `value`."""
     import subprocess
     env = dict(os.environ, STEPS="6", ROOFLINE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c1", "c4", "c5", "c5x"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c1", "c1api", "c4", "c5", "c5x"], capture_output=True, text=True,
                        timeout=timeout_s, env=env, cwd=ROOT)
     out = []
     for line in r.stdout.splitlines():

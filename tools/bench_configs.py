@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements for the other BASELINE.json configs (bench.py itself stays on configs[1]):
   c1  ResNet-18 image-wise counter, batch 8, CE+MSE, BN train, Adam            (configs[0])
+  c1api the same step through train.train_image with the driver's torch.optim.Adam: eager / train.use_graphed_steps(True)
   c2f ResNet-50 tile classifier, reference-default frozen encoder (fwd + fc bwd)
   c2s selection pass: eval fwd + softmax + adaptive top-k on 64-tile bags
   c4  EfficientNet-B3 tile classifier, bag 64, BN train                          (configs[3])
@@ -76,7 +77,7 @@ def tiles(n, size=299, seed=1234):
     return base.repeat((n + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:n].contiguous().to(dev)
 
 
-which = sys.argv[1:] or ["c1", "c2f", "c2s", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
+which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
@@ -103,6 +104,32 @@ if "c1" in which:
     gstep = GraphedStep(s1g_body, (x, cls, counts.float()))
     cf = counts.float()
     run("c1g same step as one HIP graph (GraphedStep)", lambda: gstep(x, cls, cf), 8, "images/s")
+if "c1api" in which:
+    # the reference-shaped loop itself (cellsegmentation_amd.train.train_image, train/train.py:51-105) with the driver's own optimizer
+    # (torch.optim.Adam, host step counts): eager, and with train.use_graphed_steps(True) -- zero_grad..backward replayed as one graph
+    from cellsegmentation_amd import train as T
+
+    class _L(list):
+        def __init__(self, b, n):
+            super().__init__(b)
+            self.dataset = range(n)
+    x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
+    nb = 60
+    for graphed in (False, True):
+        m = fill(R.MILresnet18()); m.setmode("image"); m.train()
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=8e-5, weight_decay=1e-4)
+        prev = T.use_graphed_steps(graphed)
+        ld = _L([(x, cls, counts)] * nb, 8 * nb)
+        T.train_image(ld, 0, 2, m, dev, torch.nn.CrossEntropyLoss(), torch.nn.MSELoss(), opt, None, 1.0, 1.0)      # warm (and capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T.train_image(ld, 1, 2, m, dev, torch.nn.CrossEntropyLoss(), torch.nn.MSELoss(), opt, None, 1.0, 1.0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nb
+        T.use_graphed_steps(prev)
+        print(json.dumps({"config": "c1api train.train_image(...) epoch of 60 batches of 8, torch.optim.Adam, "
+                                    + ("train.use_graphed_steps(True)" if graphed else "eager (default)"),
+                          "value": round(8 / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3)}), flush=True)
 if "c2g" in which:
     # the headline step (bench.py: ResNet-50 tile, trainable trunk, freeze_bn) eager and as one HIP graph: how much of the step is launch gaps / host
     from cellsegmentation_amd.graphed import GraphedStep
