@@ -46,16 +46,24 @@ class _Runner:
 
     def __init__(self, model, optimizer, body):
         self.model, self.optimizer, self.body = model, optimizer, body
-        self.seen, self.graphs = {}, {}
+        self.seen, self.graphs, self.broken = {}, {}, False
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
 
     def __call__(self, *tensors):
         if _GRAPH_STEPS[0] and all(t.is_cuda for t in tensors):
             key = tuple((tuple(t.shape), t.dtype) for t in tensors)
             g = self.graphs.get(key)
-            if g is None and self.seen.get(key, 0) >= _WARM and len(self.graphs) < 2:
+            if g is None and self.seen.get(key, 0) >= _WARM and len(self.graphs) < 2 and not self.broken:
                 from ..graphed import GraphedGrad
-                g = self.graphs[key] = GraphedGrad(self.params, self.body, tensors)
+                try:
+                    g = self.graphs[key] = GraphedGrad(self.params, self.body, tensors)
+                except Exception as e:  # noqa: BLE001 -- e.g. a criterion that synchronises (.item()): this loop stays eager
+                    import warnings
+                    self.broken = True
+                    for p in self.params:
+                        p.grad = None
+                    warnings.warn(f"cellsegmentation_amd.train: the step could not be captured into a HIP graph ({type(e).__name__}: {e}); "
+                                  "this loop keeps running eagerly")
             if g is not None:
                 return g(*tensors)
             self.seen[key] = self.seen.get(key, 0) + 1
