@@ -432,6 +432,68 @@ def _parse_rccl_log(path, max_lines=12):
     return out
 
 
+def _rccl_graph_child(timeout_s=180):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-graph-probe"], capture_output=True, text=True, timeout=timeout_s,
+                           cwd=ROOT, env=dict(os.environ))
+    except subprocess.TimeoutExpired:
+        return {"error": f"child timed out after {timeout_s} s"}
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": f"child exited with {r.returncode}: {(r.stderr or '')[-200:]}"}
+
+
+def rccl_graph_probe(dev, steps=10):
+    """Child-process body of `rccl_world1.as_one_hip_graph` (bench.py --rccl-graph-probe): the headline step with the gradient exchange
+    on over a one-rank RCCL communicator, captured into one HIP graph -- collectives included -- and replayed."""
+    import socket
+    import torch.distributed as dist
+    from cellsegmentation_amd.graphed import GraphedStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    model = build_model(dev, torch.bfloat16)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = Adam(params, lr=5e-4, weight_decay=1e-4, capturable=True)
+    x = synth.normalise(synth.ihc_tiles(BAG, SIZE, 1234)).contiguous().to(dev)
+    labels = torch.tensor([(i * 7 + 1) % 2 for i in range(BAG)], device=dev)
+    red = GradReducer(params, force_collectives=True).attach()
+    red.broadcast_parameters(model)
+
+    def step_fn(xb, lb):
+        opt.zero_grad(set_to_none=True)
+        loss = HF.cross_entropy(model(xb, freeze_bn=True), lb, 1.0)
+        loss.backward()
+        red.reduce()
+        opt.step()
+        return loss.detach()
+
+    g = GraphedStep(step_fn, (x, labels), warmup=4, pre_replay=(opt.sync_hyper,))
+    xs, ls = g.static_inputs
+    g(xs, ls)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g(xs, ls)
+    t_host = (time.perf_counter() - t0) / steps
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"ms_per_step_with_collectives": round(dt * 1e3, 3), "tiles_per_s": round(BAG / dt, 1), "host_enqueue_ms_per_step": round(t_host * 1e3, 3),
+           "buckets_sent_inside_backward": red.launches_in_backward, "capture_error_mode": "thread_local (a process group is alive)"}
+    red.detach()
+    dist.destroy_process_group()
+    return out
+
+
 def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3, use_graph=False):
     """N = 1 only, outside the timed region: the same step with the gradient exchange switched ON over a one-rank RCCL
     communicator (`GradReducer(force_collectives=True)`: 32 MB flat buckets all-reduced from inside the HIP backward on a side
@@ -484,21 +546,15 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3, use
         times = red.collective_times()
         exposed = red.exposed_ms()
         red.time_collectives = False
-        if use_graph:
-            try:
-                from cellsegmentation_amd.graphed import GraphedStep
-                g = GraphedStep(step_fn, (x, labels), warmup=1, pre_replay=(opt.sync_hyper,))
-                g(x, labels)
-                gdt, gh = run(lambda: g(x, labels), steps)
-                graph_out = {"ms_per_step_with_collectives": round(gdt * 1e3, 3), "tiles_per_s": round(BAG / gdt, 1),
-                             "host_enqueue_ms_per_step": round(gh * 1e3, 3), "buckets_sent_inside_backward": red.launches_in_backward}
-                del g
-            except Exception as e:  # noqa: BLE001 -- the capture of RCCL collectives is the thing under test here
-                graph_out = {"error": f"{type(e).__name__}: {e}"[:300]}
     finally:
         red.detach()
         if own_pg:
             dist.destroy_process_group()
+    if use_graph:
+        # the same step captured WITH its collectives, in a CHILD process: a capture with a process group alive can take the process down
+        # (the watchdog thread's event queries are illegal inside a global-mode capture: seen once in three runs before GraphedStep
+        # switched to thread_local mode there) -- a side number must never be able to do that to the headline line
+        graph_out = _rccl_graph_child()
     return {"ms_per_step_with_collectives": round(dt * 1e3, 3), "tiles_per_s": round(BAG / dt, 1), "steps": steps,
             "host_enqueue_ms_per_step": round(t_host * 1e3, 3), "gradients_aliasing_their_bucket": f"{aliased}/{len(params)}",
             "buckets": len(red.buckets), "buckets_sent_inside_backward": early,
@@ -526,6 +582,7 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="also print a per-geometry launch table to stderr")
     ap.add_argument("--eager", action="store_true", help="enqueue every step from Python (no HIP graph); the default at N > 1")
     ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph at N > 1 too (RCCL collectives captured)")
+    ap.add_argument("--rccl-graph-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -559,6 +616,12 @@ def main():
         else:
             dist.init_process_group("gloo")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.rccl_graph_probe:
+        res = rccl_graph_probe(dev)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(res), flush=True)
+        return
 
     model = build_model(dev, dtype)
     params = [p for p in model.parameters() if p.requires_grad]

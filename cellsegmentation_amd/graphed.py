@@ -16,9 +16,28 @@ captured launches through a `pre_replay` hook (`optimizer.sync_hyper` of the HIP
 Round 5: the ResNet-50 tile step of train/train.py:29-42 (`--scratch`) is captured too (bench.py's headline; bit-for-bit equality
 with eager steps in tests/test_graphed_gpu.py): 6.0 ms of host work per step leave the critical path.
 """
+import time
+
 import torch
 
 from . import _capture, engine
+
+
+def _capture_mode():
+    """`global` (torch's default) forbids potentially unsafe HIP calls from ANY thread while a capture is open.  With a NCCL / RCCL process
+    group alive its watchdog thread polls the events of earlier collectives (hipEventQuery) every ~100 ms: inside a global-mode capture
+    that call fails with hipErrorStreamCaptureUnsupported, the watchdog throws and the PROCESS aborts (seen in bench.py's one-rank RCCL
+    side run, one run in three).  With a process group alive: let the queue drain, give the watchdog a poll interval to retire what
+    completed, and capture in `thread_local` mode (only the capturing thread is policed)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            torch.cuda.synchronize()
+            time.sleep(0.3)
+            return "thread_local"
+    except Exception:  # noqa: BLE001
+        pass
+    return "global"
 
 
 class GraphedStep:
@@ -46,7 +65,7 @@ class GraphedStep:
             hook()
         self.graph = torch.cuda.CUDAGraph()
         _capture.take()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.outputs = step_fn(*self.static_inputs)
         self._refs = _capture.take()        # cached library objects the captured launches point into (see _capture.py)
 
@@ -87,7 +106,7 @@ class GraphedGrad:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         _capture.take()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             for p in self.params:
                 p.grad = None
             outs = tuple(fn(*self.static_inputs))
