@@ -294,3 +294,27 @@ def test_decoder_convs_on_the_packed_kernels_match_the_first_generation_path(dev
         if c1 < 0.75 or c1 < c0 - 0.03:      # (both bf16 routes sit at 0.83-0.92 on the deepest decoder tensors at n = 2: measured)
             worst.append((k, round(c1, 4), round(c0, 4)))
     assert not worst, worst
+
+
+def test_inference_pass_at_the_reference_batch_of_40960_small_tiles(dev):
+    """inference_tiles' forward at the reference's own operating point (train_tile.py: tiles of 32 x 32, batch 40 960, inference.py:9-28):
+    1.3 GB activations, 10.5 M stem pixels in one launch -- the probabilities of the first and the last 64 tiles equal those of the same
+    tiles run as a batch of 64 to fp32 rounding (the Linear head picks another kernel shape at M = 40 960)."""
+    from cellsegmentation_amd import kernels as K
+    m = R.MILresnet18()
+    sd = m.state_dict()
+    synth.fill_state_dict(sd)
+    m.load_state_dict(sd)
+    m = m.to(dev).set_compute_dtype(torch.bfloat16)
+    m.setmode("tile")
+    m.eval()
+    B = 40960
+    x = synth.normalise(synth.ihc_tiles(64, 32, 7)).repeat(B // 64, 1, 1, 1).contiguous().to(dev)
+    x[-64:] = synth.normalise(synth.ihc_tiles(64, 32, 9)).to(dev)
+    with torch.no_grad():
+        p = K.softmax_prob1(m(x))
+        first, last = K.softmax_prob1(m(x[:64].contiguous())), K.softmax_prob1(m(x[-64:].contiguous()))
+    torch.cuda.synchronize()
+    assert p.shape == (B,) and bool(torch.isfinite(p).all())
+    assert float((p[:64] - first).abs().max()) < 1e-5 and float((p[-64:] - last).abs().max()) < 1e-5
+    assert torch.equal(p[:64], p[64:128])                      # the same 64 tiles repeated: bit-identical rows

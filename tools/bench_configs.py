@@ -4,6 +4,7 @@
   c1api the same step through train.train_image with the driver's torch.optim.Adam: eager / train.use_graphed_steps(True)
   c2f ResNet-50 tile classifier, reference-default frozen encoder (fwd + fc bwd)
   c2s selection pass: eval fwd + softmax + adaptive top-k on 64-tile bags
+  c2i the inference pass at the reference's own tile size and batch: 40 960 tiles of 32 x 32 per forward
   c4  EfficientNet-B3 tile classifier, bag 64, BN train                          (configs[3])
   c5  ResNet-50 encoder-decoder, batch 8 at 299x299, Dice, decoder training      (configs[4], per GPU)
   c4g / c5g the c4 / c5 step replayed as one HIP graph
@@ -77,7 +78,7 @@ def tiles(n, size=299, seed=1234):
     return base.repeat((n + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:n].contiguous().to(dev)
 
 
-which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
+which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c2i", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
@@ -173,6 +174,17 @@ if "c2s" in which:
             p = HF.K.softmax_prob1(m(x))
         I.select_topk(p, groups, labels, 1, 30, dev)
     run("c2s selection pass: eval fwd + softmax + adaptive top-k, 4 bags x 64 tiles", s3, 256, "tiles/s")
+if "c2i" in which:
+    # inference_tiles at the REFERENCE's own batch: 40 960 tiles of 32 x 32 per forward (train_tile.py: tile_size 32, interval 20 -> 225
+    # tiles per 299 x 299 image, ~4 M tiles per epoch; inference.py:9-28)
+    for name, ctor in (("resnet18", R.MILresnet18), ("resnet50", R.MILresnet50)):
+        m = fill(ctor()); m.setmode("tile"); m.eval()
+        x = tiles(40960, 32)
+
+        def s3i():
+            with torch.no_grad():
+                HF.K.softmax_prob1(m(x))
+        run(f"c2i {name} inference pass, batch 40960 tiles of 32x32 (the reference's tile size and batch), eval fwd + softmax", s3i, 40960, "tiles/s")
 if "c4" in which:
     m = fill(EN.MILefficientnetB3(num_classes=2)); m.setmode("tile"); m.set_encoder_grads(True); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
