@@ -5,6 +5,7 @@
   c2f ResNet-50 tile classifier, reference-default frozen encoder (fwd + fc bwd)
   c2s selection pass: eval fwd + softmax + adaptive top-k on 64-tile bags
   c2i the inference pass at the reference's own tile size and batch: 40 960 tiles of 32 x 32 per forward
+  c2t the tile-training step at that operating point (batch 40 960 of 32 x 32)
   c4  EfficientNet-B3 tile classifier, bag 64, BN train                          (configs[3])
   c5  ResNet-50 encoder-decoder, batch 8 at 299x299, Dice, decoder training      (configs[4], per GPU)
   c4g / c5g the c4 / c5 step replayed as one HIP graph
@@ -78,7 +79,7 @@ def tiles(n, size=299, seed=1234):
     return base.repeat((n + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:n].contiguous().to(dev)
 
 
-which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c2i", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
+which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c2i", "c2t", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
@@ -185,6 +186,24 @@ if "c2i" in which:
             with torch.no_grad():
                 HF.K.softmax_prob1(m(x))
         run(f"c2i {name} inference pass, batch 40960 tiles of 32x32 (the reference's tile size and batch), eval fwd + softmax", s3i, 40960, "tiles/s")
+if "c2t" in which:
+    # the tile-training step at the reference's own operating point: train_tile.py's loader hands out batches of 40 960 tiles of 32 x 32
+    # (-b 40960, -t 32); --scratch semantics (whole trunk trains, BN frozen) and the default frozen encoder
+    for name, ctor, scratch in (("resnet18", R.MILresnet18, True), ("resnet50", R.MILresnet50, True), ("resnet50", R.MILresnet50, False)):
+        m = fill(ctor()); m.setmode("tile"); m.train()
+        if scratch:
+            m.set_encoder_grads(True)
+        x = tiles(40960, 32); y = torch.tensor([(i * 7 + 1) % 2 for i in range(40960)], device=dev)
+        opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
+
+        def s2t():
+            opt.zero_grad(set_to_none=True)
+            HF.cross_entropy(m(x, freeze_bn=True), y).backward()
+            opt.step()
+        run(f"c2t {name} tile training step, batch 40960 tiles of 32x32 (the reference's -b / -t defaults), " + ("--scratch" if scratch else "frozen encoder"),
+            s2t, 40960, "tiles/s")
+        del m, opt, x, y
+        torch.cuda.empty_cache()
 if "c4" in which:
     m = fill(EN.MILefficientnetB3(num_classes=2)); m.setmode("tile"); m.set_encoder_grads(True); m.train()
     x = tiles(64); y = torch.tensor([i % 2 for i in range(64)], device=dev)
