@@ -89,7 +89,8 @@ _SIGNATURES = {
     "cs_gap_avgmax_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cs_gap_avgmax_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cs_linear_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "cs_linear_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cs_linear_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "cs_linear_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "cs_loss_words": (c_int, []),
     "cs_softmax_ce": (c_int, [_P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "cs_softmax_prob1": (c_int, [_P, _P, c_int, c_int, _P]),

@@ -98,9 +98,10 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 template <int MODE>
 __device__ __forceinline__ void linear_tile_body(float (*At)[68], float (*Bt)[68], unsigned bx, unsigned by, const float* __restrict__ a0,
                                                  const float* __restrict__ a1, const float* __restrict__ b0, const float* __restrict__ bias,
-                                                 float* __restrict__ out, float* __restrict__ out2, int M, int N, int K, int act, int accumulate) {
-    // I x J outputs, contraction length L
-    const int I = MODE == 2 ? N : M, J = MODE == 0 ? N : K, L = MODE == 0 ? K : (MODE == 1 ? N : M);
+                                                 float* __restrict__ out, float* __restrict__ out2, int M, int N, int K, int act, int accumulate,
+                                                 int lb = 0, int le = -1) {
+    // I x J outputs, contraction length L (or its slice [lb, le), lb a multiple of 64: the split-M weight gradient)
+    const int I = MODE == 2 ? N : M, J = MODE == 0 ? N : K, L = le >= 0 ? le : (MODE == 0 ? K : (MODE == 1 ? N : M));
     const int i0 = (int)bx * 64, j0 = (int)by * 64;
     const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4;
     float acc[4][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -108,7 +109,7 @@ __device__ __forceinline__ void linear_tile_body(float (*At)[68], float (*Bt)[68
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
-    for (int l0 = 0; l0 < L; l0 += 64) {
+    for (int l0 = lb; l0 < L; l0 += 64) {
         __syncthreads();
 #pragma unroll 4
         for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -177,6 +178,38 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float At[64][68];
     __shared__ __attribute__((aligned(16))) float Bt[64][68];
     linear_tile_body<MODE>(At, Bt, blockIdx.x, blockIdx.y, a0, a1, b0, bias, out, out2, M, N, K, act, accumulate);
+}
+
+// Weight gradient of a Linear with a LONG batch axis (round 5): dw[n][k] = sum_m g[m][n] x[m][k] contracts over the M rows -- 64 in the
+// bags of BASELINE's configs, but 8 192 - 40 960 at the reference's own operating point (train_tile.py -b 40960: the squeeze-excitation
+// layers of an EfficientNet encoder then see one row per TILE).  A handful of 64 x 64 output tiles walking thousands of rows one 64-row step
+// after the other took 1.8 - 3.3 ms per launch (76 of the 93 ms of an EfficientNet-B0 step at batch 8 192).  Here blockIdx.z cuts the rows
+// into slices of `rows_per_split` (a multiple of 64); slice s leaves its partial dw / db in ws[s] and linear_splitm_fold_kernel adds the
+// slices in order (bitwise reproducible).
+__global__ __launch_bounds__(256) void linear_dw_splitm_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                                               float* __restrict__ ws, float* __restrict__ wsb, int M, int N, int K, int act,
+                                                               int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) float At[64][68];
+    __shared__ __attribute__((aligned(16))) float Bt[64][68];
+    const int s = blockIdx.z;
+    const int lb = s * rows_per_split;
+    int le = lb + rows_per_split;
+    if (le > M) le = M;
+    linear_tile_body<2>(At, Bt, blockIdx.x, blockIdx.y, dy, y, x, nullptr, ws + (long long)s * N * K, wsb + (long long)s * N, M, N, K, act, 0, lb, le);
+}
+__global__ __launch_bounds__(256) void linear_splitm_fold_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, int S, long long NK, int N,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NK) {
+        float t = accumulate ? dw[i] : 0.f;
+        for (int s = 0; s < S; ++s) t += ws[(long long)s * NK + i];
+        dw[i] = t;
+    }
+    if (db && i < N) {
+        float t = accumulate ? db[i] : 0.f;
+        for (int s = 0; s < S; ++s) t += wsb[(long long)s * N + i];
+        db[i] = t;
+    }
 }
 
 // dx and dw of one Linear in ONE launch: the two products are independent, but as two launches they ran one after the other -- two chains
@@ -390,11 +423,43 @@ extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, flo
     return CS_OK;
 }
 
+// row slices of the split-M weight gradient: 1 (no split) up to 512 rows, else slices of >= 256 rows (multiples of 64), at most 128 of them
+static int lin_dw_rows_per_split(int M) {
+    if (M <= 512) return M;
+    int s = (M + 255) / 256;
+    if (s > 128) s = 128;
+    return ((M + s - 1) / s + 63) / 64 * 64;
+}
+extern "C" size_t cs_linear_bwd_workspace(int M, int N, int K) {
+    if (M <= 512 || N <= 0 || K <= 0) return 0;
+    const int rps = lin_dw_rows_per_split(M);
+    const int S = (M + rps - 1) / rps;
+    return (size_t)S * ((size_t)N * K + (size_t)N) * sizeof(float);
+}
+
 extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
-                             float* db, int M, int N, int K, int accumulate, void* stream) {
+                             float* db, int M, int N, int K, int accumulate, float* workspace, void* stream) {
     CS_CHECK_ARG(dy && M > 0 && N > 0 && K > 0, "linear_bwd: bad arguments");
     CS_CHECK_ARG(act == CS_ACT_NONE || y, "linear_bwd: an output activation needs y (SiLU: the pre-activation)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw && M > 512) {
+        // long batch axis: dx on its own, dw over row slices + an ordered fold (linear_dw_splitm_kernel)
+        CS_CHECK_ARG(x && workspace, "linear_bwd: dw over more than 512 rows needs x and a workspace of cs_linear_bwd_workspace() bytes");
+        if (dx) {
+            const int rc = cs_linear_bwd(x, w, dy, y, act, dx, nullptr, nullptr, M, N, K, 0, nullptr, stream);
+            if (rc != CS_OK) return rc;
+        }
+        const int rps = lin_dw_rows_per_split(M);
+        const int S = (M + rps - 1) / rps;
+        float* wsb = workspace + (size_t)S * N * K;
+        hipLaunchKernelGGL(linear_dw_splitm_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)S), dim3(256), 0, st, dy, y, x,
+                           workspace, wsb, M, N, K, act, rps);
+        CS_LAUNCH_CHECK();
+        const long long NK = (long long)N * K;
+        hipLaunchKernelGGL(linear_splitm_fold_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, st, workspace, wsb, S, NK, N, dw, db, accumulate);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (dx && dw) {
         CS_CHECK_ARG(w && x, "linear_bwd: dx needs w, dw needs x");
         const bool dxt = (long long)M * K >= 1024 && lin_use_tiles(M, K, N), dwt = (long long)N * K >= 1024 && lin_use_tiles(N, K, M);

@@ -875,7 +875,10 @@ def linear_bwd(x, w, dy, y=None, act=CS_ACT_NONE, need_dx=True, need_dw=True, ne
     dx = torch.empty((M, K), dtype=torch.float32, device=x.device) if need_dx else None
     dw = torch.empty((N, K), dtype=torch.float32, device=x.device) if (need_dw or need_db) else None
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
-    _lib.check(_lib.load().cs_linear_bwd(_p(x), _p(w), _p(dy), _p(y), act, _p(dx), _p(dw), _p(db), M, N, K, 0, _stream()),
+    lib = _lib.load()
+    nws = lib.cs_linear_bwd_workspace(M, N, K) if dw is not None else 0          # (> 512 rows: row slices of the weight gradient)
+    ws = torch.empty((nws // 4,), dtype=torch.float32, device=x.device) if nws else None
+    _lib.check(lib.cs_linear_bwd(_p(x), _p(w), _p(dy), _p(y), act, _p(dx), _p(dw), _p(db), M, N, K, 0, _p(ws), _stream()),
                "linear_bwd")
     return dx, dw, db
 

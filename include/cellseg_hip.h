@@ -348,8 +348,12 @@ int cs_linear_fwd(const float* x, const float* w, const float* b, float* y, floa
                   void* stream);
 /* dx[M][K] = g @ w (nullable dx); dw[N][K] (+)= g^T @ x; db[N] (+)= colsum(g), g = dy through the output
  * activation: `y` = stored output for ReLU / sigmoid, stored PRE-activation for SiLU. */
+/* `workspace`: cs_linear_bwd_workspace(M, N, K) bytes (0 up to 512 rows: NULL is fine).  With a long batch axis -- the reference hands its
+ * tile loops batches of 40 960 (train_tile.py -b), so the squeeze-excitation layers of an EfficientNet encoder see M in the thousands --
+ * the weight gradient is cut into row slices whose partial results land there and are added in slice order (ABI 6). */
+size_t cs_linear_bwd_workspace(int M, int N, int K);
 int cs_linear_bwd(const float* x, const float* w, const float* dy, const float* y, int act, float* dx, float* dw,
-                  float* db, int M, int N, int K, int accumulate, void* stream);
+                  float* db, int M, int N, int K, int accumulate, float* workspace, void* stream);
 /* CrossEntropyLoss(mean) * gamma on logits[M][C]; dlogits nullable.  `loss` (here and in cs_mse): cs_loss_words() = 16 floats, all
  * overwritten -- the value in loss[0], the rest is the exact accumulator the workgroups' partial sums meet in (round 5: the value of a
  * launch with more than one workgroup no longer depends on their arrival order). */

@@ -119,7 +119,9 @@ def test_linear_ce_mse(dev):
     assert abs(float(lw.cpu()) - 148.59375) < 1e-3
 
 
-@pytest.mark.parametrize("shape", [(64, 2304, 96), (64, 96, 2304), (50, 130, 70), (64, 40, 10), (17, 64, 2048)])
+@pytest.mark.parametrize("shape", [(64, 2304, 96), (64, 96, 2304), (50, 130, 70), (64, 40, 10), (17, 64, 2048),
+                                   # a long batch axis (the reference's tile batches, train_tile.py -b 40960): the weight gradient over row slices
+                                   (8192, 48, 1152), (5000, 10, 40), (1000, 70, 130), (40960, 8, 192)])
 @pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "silu"])
 def test_linear_tiled_products(shape, act, dev):
     """The 64 x 64 LDS-tiled Linear kernels (forward, dx, dw/db; >= 1024 outputs -- the squeeze-excitation layers of EfficientNet
@@ -139,7 +141,7 @@ def test_linear_tiled_products(shape, act, dev):
     saved = pred if act == "silu" else yd                   # cs_linear_bwd: the pre-activation for SiLU, the output otherwise
     dx, dw, db = K.linear_bwd(xd, wd, dy.to(dev), saved, code)
     torch.cuda.synchronize()
-    tol = 2e-5
+    tol = 2e-5 if M <= 512 else 2e-4             # (fp32 sums over thousands of rows: torch's own order differs too)
     assert float((yd.cpu() - y.detach()).abs().max()) < tol * max(1.0, float(y.detach().abs().max()))
     assert float((pred.cpu() - pre.detach()).abs().max()) < tol * max(1.0, float(pre.detach().abs().max()))
     assert float((dx.cpu() - x.grad).abs().max()) < tol * max(1.0, float(x.grad.abs().max()))
