@@ -423,16 +423,22 @@ extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, flo
     return CS_OK;
 }
 
-// row slices of the split-M weight gradient: 1 (no split) up to 512 rows, else slices of >= 256 rows (multiples of 64), at most 128 of them
-static int lin_dw_rows_per_split(int M) {
+// row slices of the split-M weight gradient: none up to 512 rows; else enough slices for ~1024 workgroups over the output tiles, each of
+// >= 256 rows (a multiple of 64), at most 128 slices (the fold reads slices x outputs floats: 57 us per launch with 128 slices of a
+// 1152 x 48 gradient)
+static int lin_dw_rows_per_split(int M, int N, int K) {
     if (M <= 512) return M;
-    int s = (M + 255) / 256;
+    const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
+    long long s = 1024 / (tiles > 0 ? tiles : 1);
+    if (s < 2) s = 2;
     if (s > 128) s = 128;
-    return ((M + s - 1) / s + 63) / 64 * 64;
+    long long rps = ((M + s - 1) / s + 63) / 64 * 64;
+    if (rps < 256) rps = 256;
+    return (int)rps;
 }
 extern "C" size_t cs_linear_bwd_workspace(int M, int N, int K) {
     if (M <= 512 || N <= 0 || K <= 0) return 0;
-    const int rps = lin_dw_rows_per_split(M);
+    const int rps = lin_dw_rows_per_split(M, N, K);
     const int S = (M + rps - 1) / rps;
     return (size_t)S * ((size_t)N * K + (size_t)N) * sizeof(float);
 }
@@ -449,7 +455,7 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
             const int rc = cs_linear_bwd(x, w, dy, y, act, dx, nullptr, nullptr, M, N, K, 0, nullptr, stream);
             if (rc != CS_OK) return rc;
         }
-        const int rps = lin_dw_rows_per_split(M);
+        const int rps = lin_dw_rows_per_split(M, N, K);
         const int S = (M + rps - 1) / rps;
         float* wsb = workspace + (size_t)S * N * K;
         hipLaunchKernelGGL(linear_dw_splitm_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)S), dim3(256), 0, st, dy, y, x,

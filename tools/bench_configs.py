@@ -6,6 +6,7 @@
   c2s selection pass: eval fwd + softmax + adaptive top-k on 64-tile bags
   c2i the inference pass at the reference's own tile size and batch: 40 960 tiles of 32 x 32 per forward
   c2t the tile-training step at that operating point (batch 40 960 of 32 x 32)
+  c4t the same for EfficientNet-B0 / -B3
   c4  EfficientNet-B3 tile classifier, bag 64, BN train                          (configs[3])
   c5  ResNet-50 encoder-decoder, batch 8 at 299x299, Dice, decoder training      (configs[4], per GPU)
   c4g / c5g the c4 / c5 step replayed as one HIP graph
@@ -202,6 +203,21 @@ if "c2t" in which:
             opt.step()
         run(f"c2t {name} tile training step, batch 40960 tiles of 32x32 (the reference's -b / -t defaults), " + ("--scratch" if scratch else "frozen encoder"),
             s2t, 40960, "tiles/s")
+        del m, opt, x, y
+        torch.cuda.empty_cache()
+if "c4t" in which:
+    # EfficientNet tile training at the reference's own operating point (train_tile.py -b 40960 -t 32): the squeeze-excite Linear layers see a
+    # batch axis of 40 960 rows, whose weight gradient runs over row slices (cs_linear_bwd + workspace)
+    for name, ctor in (("efficientnet_b0", EN.MILefficientnetB0), ("efficientnet_b3", EN.MILefficientnetB3)):
+        m = fill(ctor(num_classes=2)); m.setmode("tile"); m.set_encoder_grads(True); m.train()
+        x = tiles(40960, 32); y = torch.tensor([(i * 7 + 1) % 2 for i in range(40960)], device=dev)
+        opt = make_adam([p for p in m.parameters() if p.requires_grad], 5e-4, 1e-4)
+
+        def s4t():
+            opt.zero_grad(set_to_none=True)
+            HF.cross_entropy(m(x, freeze_bn=True), y).backward()
+            opt.step()
+        run(f"c4t {name} tile training step, batch 40960 tiles of 32x32 (the reference's -b / -t defaults), whole trunk trains", s4t, 40960, "tiles/s")
         del m, opt, x, y
         torch.cuda.empty_cache()
 if "c4" in which:
