@@ -556,7 +556,7 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3, use
         # switched to thread_local mode there) -- a side number must never be able to do that to the headline line
         graph_out = _rccl_graph_child()
     return {"ms_per_step_with_collectives": round(dt * 1e3, 3), "tiles_per_s": round(BAG / dt, 1), "steps": steps,
-            "host_enqueue_ms_per_step": round(t_host * 1e3, 3), "gradients_aliasing_their_bucket": f"{aliased}/{len(params)}",
+            "host_enqueue_ms_per_step": round(t_host * 1e3, 3), "gradients_aliasing_their_bucket": f"{aliased}/{sum(1 for p in params if p.grad is not None)}",
             "buckets": len(red.buckets), "buckets_sent_inside_backward": early,
             "allreduce_ms_per_step": round(sum(t for _, t in times), 4), "exposed_ms": round(exposed, 4),
             "per_bucket": [{"mbytes": round(n / 1e6, 2), "ms": round(t, 4)} for n, t in times],

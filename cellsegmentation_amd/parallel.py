@@ -15,7 +15,8 @@ Gradients live in a few flat fp32 buckets (fewer, larger collectives suit point-
   ResNet-50 -- are on the wire long before the stem's gradients exist.
 * ``reduce()`` (after ``backward()``, before ``optimizer.step()``) sends whatever has not gone yet
   (gradients produced outside the engine, e.g. the classifier head), waits for the side stream and makes
-  every ``p.grad`` hold the average.
+  every ``p.grad`` hold the average (RCCL: ``ReduceOp.AVG``, the division happens inside the collective; gloo: SUM and one scaling
+  pass).  A trainable parameter that received no gradient keeps ``grad is None`` as in a one-process run.
 
 One ``backward()`` per ``reduce()`` (the reference's loops: zero_grad -> backward -> step), with
 ``zero_grad(set_to_none=True)`` (torch's default) so autograd adopts the bucket slices as ``.grad``
@@ -32,12 +33,14 @@ _ALIGN = 64      # floats: every bucket slice starts on a 256-byte boundary
 
 
 class _Bucket:
-    __slots__ = ("flat", "items", "views", "pending", "launched", "streams")
+    __slots__ = ("flat", "items", "views", "ptrs", "dirty", "pending", "launched", "streams")
 
     def __init__(self, n, device):
         self.flat = torch.zeros((n,), dtype=torch.float32, device=device)
         self.items = []          # (param, offset, numel)
         self.views = []          # the slice of `flat` shaped like each parameter (made once: slicing costs microseconds per call)
+        self.ptrs = []           # data_ptr() of each slice
+        self.dirty = []          # the slice has held a gradient since it was last zero (`flat` starts as zeros)
         self.pending = 0
         self.launched = False
         self.streams = set()     # streams whose kernels wrote gradients into this bucket since the last reduce()
@@ -97,7 +100,9 @@ class GradReducer:
                 b.items.append((p, o, n))
                 view = b.flat[o:o + n].view_as(p)
                 b.views.append(view)
-                self._slot[id(p)] = (b, view, view.data_ptr())
+                b.ptrs.append(view.data_ptr())
+                b.dirty.append(False)
+                self._slot[id(p)] = (b, view, view.data_ptr(), len(b.views) - 1)
             self.buckets.append(b)
 
         for i, p in enumerate(ordered):
@@ -144,9 +149,10 @@ class GradReducer:
         s = self._slot.get(id(param))
         if s is None or not self._active or param.grad is not None:      # an existing .grad may BE this slice: never write under it
             return None
-        b, view, _ = s
+        b, view, _, i = s
         if b.launched:
             raise RuntimeError("GradReducer: a second backward() before reduce(); call reduce() once per backward")
+        b.dirty[i] = True
         return view
 
     def deliver(self, param, grad):
@@ -157,9 +163,10 @@ class GradReducer:
         if not self._layout_final and id(param) not in self._order_ids:
             self._order_ids.add(id(param))
             self._order.append(param)
-        b, view, vptr = s
+        b, view, vptr, i = s
         if b.launched:
             raise RuntimeError("GradReducer: a second backward() before reduce(); call reduce() once per backward")
+        b.dirty[i] = True
         if param.grad is not None:
             # autograd will ACCUMULATE `grad` into .grad (which may alias our slice) after we return: leave the slice alone,
             # send nothing of this bucket early; reduce() picks the total up from .grad
@@ -178,8 +185,19 @@ class GradReducer:
         return view.detach()
 
     # ------------------------------------------------------------------ collectives
+    def _all_reduce_mean(self, t):
+        """SUM over the ranks / world, in place.  RCCL divides inside the collective (ReduceOp.AVG: no second pass over the bucket);
+        gloo has no AVG."""
+        if self._avg is None:
+            self._avg = dist.get_backend(self.group) == "nccl"
+        if self._avg:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                t.mul_(1.0 / self.world)
+
     def _launch(self, b):
-        inv = 1.0 / self.world
         if b.flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
@@ -190,16 +208,15 @@ class GradReducer:
                 if self.time_collectives:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self._stream)
-                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
-                b.flat.mul_(inv)
+                self._all_reduce_mean(b.flat)
                 if self.time_collectives:
                     e1.record(self._stream)
                     self._timed.append((b.flat.numel() * 4, e0, e1))
         else:
-            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
-            b.flat.mul_(inv)
+            self._all_reduce_mean(b.flat)
         b.launched = True
 
+    _avg = None
     _layout_final = False
     time_collectives = False          # True: bracket every bucket's all-reduce (+ scale) with events on the side stream
 
@@ -223,43 +240,47 @@ class GradReducer:
         """All-reduce(SUM)/world of every .grad, in place (finishes what backward has not already sent)."""
         if not self._active:
             return
-        early = [b for b in self.buckets if b.launched]
-        sent_early = len(early)
-        inv = 1.0 / self.world
+        sent_early = sum(1 for b in self.buckets if b.launched)
         # Gradients delivered from inside backward are expected to have been ADOPTED by autograd as an alias of their bucket slice.
         # AccumulateGrad does not always adopt: it clones when somebody else still references the tensor, and it SUMS when the
         # parameter also received a gradient from plain autograd in the same backward (or under create_graph).  Then `.grad`
         # holds the rank-local total and the slice only what the engine wrote.  For a bucket that is still here the pack below
         # takes the total from `.grad`; for a bucket that already left, the parameter's `.grad` is all-reduced on its own (same
         # program on every rank: the same parameters take this path everywhere, in the same order).
-        stragglers = []
-        for b in early:
-            for (p, _, _), view in zip(b.items, b.views):
-                g = p.grad
-                if g is not None and g.data_ptr() != self._slot[id(p)][2]:
-                    stragglers.append(g)
+        # A parameter WITHOUT a gradient (trainable but not part of this mode's forward: the decoder in tile mode) keeps
+        # `grad is None`, exactly as in a one-process run -- the optimizer skips it; its slice travels as zeros (written once:
+        # `flat` starts as zeros and is only re-zeroed after the slice has held a gradient).  Pure data parallelism runs the same
+        # program on every rank, so such a parameter has no gradient anywhere.
+        stragglers, back = [], []
         for b in self.buckets:
-            if b.launched:
-                continue
-            # pack what the engine did not write in place: gradients that came through plain autograd, gradients autograd did not
-            # adopt, or every gradient when this step could not overlap (accumulation into an existing .grad)
-            for (p, _, _), view in zip(b.items, b.views):
-                if p.grad is None:
-                    view.zero_()
-                elif p.grad.data_ptr() != view.data_ptr():
-                    view.copy_(p.grad)
-            self._launch(b)
+            early = b.launched
+            dirty = b.dirty
+            for i, (item, vptr) in enumerate(zip(b.items, b.ptrs)):
+                g = item[0].grad
+                if g is None:
+                    if dirty[i] and not early:
+                        b.views[i].zero_()
+                        dirty[i] = False
+                elif g.data_ptr() != vptr:
+                    if early:
+                        stragglers.append(g)
+                    else:
+                        # pack what the engine did not write in place: gradients that came through plain autograd, gradients autograd
+                        # did not adopt, or every gradient when this step could not overlap (accumulation into an existing .grad)
+                        b.views[i].copy_(g)
+                        dirty[i] = True
+                        back.append((g, b.views[i]))
+            if not early:
+                self._launch(b)
         if stragglers:
             if stragglers[0].is_cuda:
                 self._stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._stream):
                     for g in stragglers:
-                        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                        g.mul_(inv)
+                        self._all_reduce_mean(g)
             else:
                 for g in stragglers:
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                    g.mul_(inv)
+                    self._all_reduce_mean(g)
         self.unadopted_after_early_launch = len(stragglers)
         if self._stream is not None:
             cur = torch.cuda.current_stream()
@@ -272,14 +293,8 @@ class GradReducer:
                 self._exposed.append((ea, eb))
             else:
                 cur.wait_stream(self._stream)
-        done = {id(g) for g in stragglers}
-        for b in self.buckets:
-            for (p, _, _), view in zip(b.items, b.views):
-                g = p.grad
-                if g is None:
-                    p.grad = view.clone()
-                elif g.data_ptr() != self._slot[id(p)][2] and id(g) not in done:
-                    g.copy_(view)              # (skipped only where .grad IS the slice: nothing to copy)
+        for g, view in back:
+            g.copy_(view)                  # (.grad that IS the slice: nothing to copy)
         if self._attached and not self._layout_final and self._order:
             # first attached step done: lay the buckets out in the order the engine finishes gradients (everything the engine
             # never reported goes last, it is only available after backward anyway).  Old slices that .grad may still alias

@@ -33,8 +33,16 @@ def _worker(rank, world, port, q):
     red.reduce()
     ok = True
     for i, p in enumerate(params):
-        want = (1.0 + 2.0) / 2 if i != 1 else (0.0 + 0.0) / 2
-        ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+        if i == 1:
+            ok = ok and p.grad is None                # no gradient on any rank: stays None, the optimizer skips it as in a one-process run
+        else:
+            ok = ok and torch.allclose(p.grad, torch.full_like(p, (1.0 + 2.0) / 2))
+    # a slice that held a gradient in an earlier step travels as zeros again once its parameter has none (and .grad stays None)
+    for i, p in enumerate(params):
+        p.grad = None if i == 0 else torch.full_like(p, float(rank + 1))
+    red.reduce()
+    b, view, _, _ = red._slot[id(params[0])]
+    ok = ok and params[0].grad is None and not bool(view.abs().max() > 0) and torch.allclose(params[1].grad, torch.full_like(params[1], 1.5))
     gathered = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(gathered, w0)
     ok = ok and torch.equal(gathered[0], gathered[1])  # broadcast made the replicas identical

@@ -57,9 +57,9 @@ def _worker_body(rank, world, port, q):
         for p in params:
             p.grad = None
         torch.nn.functional.cross_entropy(m(xs[r], freeze_bn=True), ys[r]).backward()
-        return [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]      # tile mode leaves the image heads unused
+        return [p.grad.clone() if p.grad is not None else None for p in params]      # tile mode leaves the image heads unused
 
-    expect = [sum(gs) / world for gs in zip(*[local_grads(r) for r in range(world)])]      # no reducer involved
+    expect = [None if gs[0] is None else sum(gs) / world for gs in zip(*[local_grads(r) for r in range(world)])]      # no reducer involved
 
     red = GradReducer(params, bucket_bytes=4 << 20).attach()
     red.broadcast_parameters(m)
@@ -71,7 +71,10 @@ def _worker_body(rank, world, port, q):
         red.reduce()
         early.append(red.launches_in_backward)
         for p, e in zip(params, expect):
-            worst = max(worst, float((p.grad - e).abs().max() / (e.abs().max() + 1e-12)))
+            if e is None:
+                worst = max(worst, 0.0 if p.grad is None else 1.0)       # no gradient on any rank: stays None, as in a one-process run
+            else:
+                worst = max(worst, float((p.grad - e).abs().max() / (e.abs().max() + 1e-12)))
     red.detach()
     torch.cuda.synchronize()
     q.put((rank, worst, early, len(red.buckets) - red.n_rest_buckets + 1))      # (+1: the historical "all but the head's bucket")
