@@ -498,7 +498,7 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3, use
     """N = 1 only, outside the timed region: the same step with the gradient exchange switched ON over a one-rank RCCL
     communicator (`GradReducer(force_collectives=True)`: 32 MB flat buckets all-reduced from inside the HIP backward on a side
     stream).  A world of one moves no bytes over xGMI, so what this prices is everything else the N > 1 path adds to a step: the
-    RCCL kernel launches, the side-stream hand-offs and the 1/world scaling pass.  With `use_graph` the step -- collectives
+    RCCL kernel launches (ReduceOp.AVG: the 1/world scale happens inside the collective) and the side-stream hand-offs.  With `use_graph` the step -- collectives
     included -- is additionally captured into one HIP graph and replayed (what `bench.py --gpus N --graph` runs).  Never `value`."""
     import socket
     import torch.distributed as dist
@@ -562,7 +562,7 @@ def rccl_world1_side(dev, model, params, opt, x, labels, steps=10, warmup=3, use
             "per_bucket": [{"mbytes": round(n / 1e6, 2), "ms": round(t, 4)} for n, t in times],
             "rccl_log": _parse_rccl_log(rccl_log),
             "as_one_hip_graph": graph_out,
-            "note": "one-rank RCCL communicator (backend nccl): all-reduce + 1/world scale per bucket, event-timed on the side stream; "
+            "note": "one-rank RCCL communicator (backend nccl): all-reduce (ReduceOp.AVG) per bucket, event-timed on the side stream; "
                     "top-level figures = eager step, as_one_hip_graph = the same step with its collectives captured and replayed"}
 
 

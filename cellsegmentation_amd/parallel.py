@@ -123,7 +123,6 @@ class GradReducer:
             b.launched = False
             b.streams = set()
         self._overlap_ok = True
-        self._delivered = set()
 
     def broadcast_parameters(self, module, src=0):
         """DDP-constructor semantics: rank `src`'s parameters and buffers everywhere."""
@@ -176,7 +175,6 @@ class GradReducer:
             view.copy_(grad)
         if (_engine.WGRAD_SIDE_STREAM or _engine.WGRAD_SIDE_MAX_M > 0) and view.is_cuda:
             b.streams.add(torch.cuda.current_stream())      # (opt-in engine mode: weight gradients finished on a side stream)
-        self._delivered.add(id(param))
         b.pending -= 1
         if b.pending == 0 and self._overlap_ok and self._layout_final:
             self._launch(b)

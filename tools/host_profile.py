@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side profile of the headline step (bench.py's model and step): cProfile over N steps, top functions by own time, and the
-host time to ENQUEUE a step against its GPU time.  python tools/host_profile.py [steps]"""
+host time to ENQUEUE a step against its GPU time.  [CFG=c1] [REDUCER=1] python tools/host_profile.py [steps]"""
 import cProfile
 import io
 import os
@@ -45,10 +45,25 @@ else:
     x = synth.normalise(synth.ihc_tiles(bench.BAG, bench.SIZE, 1234)).contiguous().to(dev)
     labels = torch.tensor([(i * 7 + 1) % 2 for i in range(bench.BAG)], device=dev)
 
+    red = None
+    if os.environ.get("REDUCER", "0") != "0":
+        # the one-rank RCCL gradient exchange switched on (what the N > 1 step adds on the host)
+        import socket
+        import torch.distributed as dist
+        from cellsegmentation_amd.parallel import GradReducer
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        red = GradReducer(params, force_collectives=True).attach()
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss = HF.cross_entropy(model(x, freeze_bn=True), labels, 1.0)
         loss.backward()
+        if red is not None:
+            red.reduce()
         opt.step()
 
 

@@ -2,7 +2,7 @@
 # one box: the eager step with / without the one-rank RCCL exchange, wall clock for several channel caps, then rocprofv3 tables of both
 out=gpurun_out/rccl_side; mkdir -p $out; export TMPDIR=/tmp
 for r in 0 1 0 1; do REDUCER=$r python3 tools/rccl_side_probe.py 30 2>/dev/null | grep reducer; done
-for c in 2 4 8 16 32; do REDUCER=1 NCCL_MAX_NCHANNELS=$c python3 tools/rccl_side_probe.py 30 2>/dev/null | grep reducer; done
+for c in 4; do REDUCER=1 NCCL_MAX_NCHANNELS=$c python3 tools/rccl_side_probe.py 30 2>/dev/null | grep reducer; done
 for r in 0 1; do
   REDUCER=$r rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$r -o p -- python3 tools/rccl_side_probe.py 20 > /dev/null 2>&1
   f=$(find $out/p$r -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/stats_$r.csv; rm -rf $out/p$r
