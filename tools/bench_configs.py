@@ -80,7 +80,7 @@ def tiles(n, size=299, seed=1234):
     return base.repeat((n + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:n].contiguous().to(dev)
 
 
-which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c2i", "c2t", "c4", "c4g", "c5", "c5g", "c5x", "c1cpu"]
+which = sys.argv[1:] or ["c1", "c1api", "c2f", "c2s", "c2i", "c2t", "c4", "c4g", "c4t", "c5", "c5g", "c5x", "c1cpu"]
 if "c1" in which:
     m = fill(R.MILresnet18()); m.setmode("image"); m.train()
     x = tiles(8); counts = torch.tensor([0, 3, 12, 40, 1, 7, 25, 230], device=dev); cls = torch.tensor([0, 1, 3, 4, 1, 2, 4, 6], device=dev)
