@@ -45,13 +45,15 @@ __device__ __forceinline__ void block_fold_atomic(const float (&a)[8], const flo
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, long long M, int C, double* __restrict__ stats,
-                                                       int rows_per_block, double* __restrict__ partial) {
+                                                       int rows_per_block, double* __restrict__ partial, int cw) {
     const int CG = C / 8;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
-        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+    {
+        // grid = (row blocks, channel chunks of <= cw 8-channel groups), red_split below
+        const int cg0 = blockIdx.y * cw;
+        const int width = (CG - cg0) < cw ? (CG - cg0) : cw;
         const int rpar = 256 / width;
         const int cg = cg0 + (int)(threadIdx.x % width);
         const int rr = threadIdx.x / width;
@@ -236,13 +238,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                             long long M, int C, double* __restrict__ sums,
-                                                            int rows_per_block, double* __restrict__ partial) {
+                                                            int rows_per_block, double* __restrict__ partial, int cw) {
     const int CG = C / 8;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    for (int cg0 = 0; cg0 < CG; cg0 += 256) {
-        const int width = (CG - cg0) < 256 ? (CG - cg0) : 256;
+    {
+        // grid = (row blocks, channel chunks of <= cw 8-channel groups), red_split below
+        const int cg0 = blockIdx.y * cw;
+        const int width = (CG - cg0) < cw ? (CG - cg0) : cw;
         const int rpar = 256 / width;
         const int cg = cg0 + (int)(threadIdx.x % width);
         const int rr = threadIdx.x / width;
@@ -384,9 +388,13 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __re
     }
 }
 
-// Up to this many workgroups a reduction adds its per-workgroup sums with fp64 atomics (<= 512 per address) instead of writing partial
-// rows for a second launch to fold: one launch less per small BatchNorm (the folds themselves already end in fp64 atomics).
+// A reduction adds its per-workgroup sums with fp64 atomics (exact accumulators: 6 per channel and row block) instead of writing
+// partial rows for a second launch to fold -- one launch less per small BatchNorm -- as long as there are at most 512 row blocks AND
+// at most 300 k atomics in the launch (~100 G atomics/s: 3 us; 38 x 38 x 288 channels with 511 row blocks = 880 k spent 10 of 34 us
+// in them, 6400 x 1392 with 100 row blocks = 835 k as long as in its 36 MB of loads).
 constexpr int kBnAtomicBlocks = 512;
+constexpr long long kBnAtomicBudget = 300000;
+inline bool red_wants_partials(int C, long long blocks) { return blocks > kBnAtomicBlocks || blocks * (long long)C * 6 > kBnAtomicBudget; }
 
 inline int fold_partial(const double* partial, int blocks, int C, double* out, hipStream_t st) {
     int chunks = blocks / 16;
@@ -396,17 +404,36 @@ inline int fold_partial(const double* partial, int blocks, int C, double* out, h
     return 0;
 }
 
-// rows per workgroup of the reductions: ~CELLSEG_BN_BLOCKS workgroups, but never fewer than 8 row steps per thread.  A thread owns one
-// 8-channel group and every rpar-th row (rpar = 256 / channel groups): with the old fixed floor of 64 rows a wide, small tensor
-// (EfficientNet stage 6/7: 6400 rows x 2304 channels) ran as 100 workgroups whose threads walked 64 rows one after the other.
-inline int rows_per_block_for(long long M, int C) {
+// Decomposition of the reductions (bn_stats_kernel, bn_bwd_reduce_kernel): channel chunks of <= 16 / 32 / 64 8-channel groups (balanced),
+// rows per workgroup for ~CELLSEG_BN_BLOCKS workgroups in all, never fewer than 8 row steps per thread.  A thread owns one 8-channel group
+// and every rpar-th row of its block (rpar = 256 / chunk width).  Round 5: until then a workgroup covered ALL channels of its rows --
+// 174 live threads, one row each, for EfficientNet's 6400 x 1392 tensors, 800 row blocks of 8 rows whose 2 x 1392 partial sums (as
+// many bytes as the tensor) went through a workspace and a fold launch: 19 us for a pass that moves 36 MB.  With chunks the same
+// tensor is 100 row blocks x 6 chunks with 8 rows in flight per chunk: 14 us.
+struct RedSplit { int chunks, cw, rpb; };
+inline RedSplit red_split(long long M, int C) {
     static const int target = cs_env_int_("CELLSEG_BN_BLOCKS", 1024);     // A/B experiments only
     const int CG = C / 8 > 0 ? C / 8 : 1;
-    const int rpar = 256 / (CG < 256 ? CG : 256);
-    long long r = (M + target - 1) / target;
-    const long long floor_rows = 8LL * (rpar > 0 ? rpar : 1);
+    RedSplit s;
+    // chunk width (measured on EfficientNet-B3's tensors, tools/bn_microbench.py): one chunk while it is at most 64 groups wide and the
+    // rows alone give >= 800 workgroups; 16-group chunks for tensors so small that the 8-step floor leaves < 450 workgroups whatever the
+    // width (fewer row blocks = fewer contributions per channel: most of those then fit the atomics budget, one launch); 32 otherwise
+    static const int forced_w = cs_env_int_("CELLSEG_BN_CW", 0);           // A/B experiments only
+    int max_w = 32;
+    if (CG <= 64 && M >= 800LL * 8 * (256 / CG)) max_w = 64;
+    else if (M * CG < 450LL * 2048) max_w = 16;
+    if (forced_w > 0) max_w = forced_w;
+    s.chunks = (CG + max_w - 1) / max_w;
+    s.cw = (CG + s.chunks - 1) / s.chunks;
+    s.chunks = (CG + s.cw - 1) / s.cw;
+    const int rpar = 256 / s.cw;
+    long long row_blocks = target / s.chunks;
+    if (row_blocks < 1) row_blocks = 1;
+    long long r = (M + row_blocks - 1) / row_blocks;
+    const long long floor_rows = 8LL * rpar;
     if (r < floor_rows) r = floor_rows;
-    return (int)r;
+    s.rpb = (int)r;
+    return s;
 }
 
 // row block of the element-wise passes: ~CELLSEG_EW_BLOCKS (2048: 8 workgroups per compute unit) blocks, at least 16 rows each
@@ -470,23 +497,25 @@ extern "C" int cs_bn_partial_fold(const double* partial, int rows, int C, double
 
 extern "C" size_t cs_bn_partial_workspace(long long M, int C) {
     if (M <= 0 || C <= 0) return 0;
-    const int rpb = rows_per_block_for(M, C);
+    const int rpb = red_split(M, C).rpb;
     const long long blocks = (M + rpb - 1) / rpb;
     // 0 = no workspace wanted: with this few workgroups cs_bn_stats / cs_bn_bwd_reduce add their sums with fp64 atomics (the ONE place
     // the rule lives: callers allocate what this function says)
-    if (blocks <= kBnAtomicBlocks) return 0;
+    if (!red_wants_partials(C, blocks)) return 0;
     return (size_t)blocks * 2 * (size_t)C * sizeof(double);
 }
 
 extern "C" int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream) {
     CS_CHECK_ARG(z && stats && M > 0 && C > 0 && C % 8 == 0, "bn_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = rows_per_block_for(M, C);
+    const RedSplit sp = red_split(M, C);
+    const int rpb = sp.rpb;
     const int blocks = (int)((M + rpb - 1) / rpb);
-    if (blocks <= kBnAtomicBlocks) workspace = nullptr;      // few workgroups: fp64 atomics straight into `stats`, no fold launch
+    if (!red_wants_partials(C, blocks)) workspace = nullptr;      // few contributions: fp64 atomics straight into `stats`, no fold launch
+    const dim3 grid((unsigned)blocks, (unsigned)sp.chunks);
     CS_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, M, C, stats, rpb, workspace),
-                  hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, M, C, stats, rpb, workspace),
+                  hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)z, M, C, stats, rpb, workspace, sp.cw),
+                  hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)z, M, C, stats, rpb, workspace, sp.cw),
                   "bn_stats");
     CS_LAUNCH_CHECK();
     if (workspace) {
@@ -547,14 +576,16 @@ extern "C" int cs_bn_bwd_reduce(const void* dy, const void* z, int dtype, const 
                                 void* stream) {
     CS_CHECK_ARG(dy && z && mean && rstd && sums && M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rpb = rows_per_block_for(M, C);
+    const RedSplit sp = red_split(M, C);
+    const int rpb = sp.rpb;
     const int blocks = (int)((M + rpb - 1) / rpb);
-    if (blocks <= kBnAtomicBlocks) workspace = nullptr;      // (as in cs_bn_stats)
+    if (!red_wants_partials(C, blocks)) workspace = nullptr;      // (as in cs_bn_stats)
+    const dim3 grid((unsigned)blocks, (unsigned)sp.chunks);
     CS_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
-                                     rstd, gamma, beta, act, M, C, sums, rpb, workspace),
-                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z,
-                                     mean, rstd, gamma, beta, act, M, C, sums, rpb, workspace),
+                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)z, mean,
+                                     rstd, gamma, beta, act, M, C, sums, rpb, workspace, sp.cw),
+                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z,
+                                     mean, rstd, gamma, beta, act, M, C, sums, rpb, workspace, sp.cw),
                   "bn_bwd_reduce");
     CS_LAUNCH_CHECK();
     if (workspace) {

@@ -78,7 +78,7 @@ size_t cs_bn_accum_words(int C);
 int cs_bn_accum_read(const double* accum, int C, double* out, void* stream);
 int cs_bn_stats(const void* z, int dtype, long long M, int C, double* stats, double* workspace, void* stream);
 /* `workspace` of cs_bn_stats / cs_bn_bwd_reduce (nullable, cs_bn_partial_workspace(M, C) bytes -- 0 where the launch has so few
- * workgroups that it adds its sums straight into the accumulator and wants none): per-workgroup partial sums are
+ * row blocks and channels that it adds its sums straight into the accumulator and wants none): per-workgroup partial sums are
  * written there and folded by a second small launch instead of ~1000 atomics per channel (3x faster on large tensors). */
 size_t cs_bn_partial_workspace(long long M, int C);
 /* mean, rstd = 1/sqrt(biased var+eps); running_* (nullable) updated in place with `momentum` and the
