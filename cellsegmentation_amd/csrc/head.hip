@@ -29,6 +29,36 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
+// SHORT contraction (K <= 64: the second Linear of a squeeze-excitation block, 6-58 inputs): one THREAD per output, k ascending with
+// one fused multiply-add per step -- the summation order of the tiled kernel, so both give the same bits.  The 64 x 64 LDS tile
+// spends ~5 us of fixed latencies (tile loads, transposed LDS stores, barrier, LDS reads) on a product of 64 x 24 x 576.
+__global__ __launch_bounds__(256) void linear_fwd_shortk_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* __restrict__ y, float* __restrict__ pre,
+                                                                int M, int N, int K, int act) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long long)M * N) return;
+    const int m = (int)(o / N), n = (int)(o - (long long)m * N);
+    const float* xr = x + (long long)m * K;
+    const float* wr = w + (long long)n * K;
+    const float bias = b ? b[n] : 0.f;
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        float xv[8], wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { xv[q] = xr[k + q]; wv[q] = wr[k + q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(xv[q], wv[q], acc);
+    }
+    for (; k < K; ++k) acc = fmaf(xr[k], wr[k], acc);
+    float v = acc + bias;
+    if (pre) pre[o] = v;
+    if (act == CS_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == CS_ACT_SILU) v = v / (1.f + expf(-v));
+    else if (act == CS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    y[o] = v;
+}
+
 // upstream gradient through the output activation; `y` is the stored OUTPUT for ReLU / sigmoid and the stored
 // PRE-activation for SiLU
 __device__ __forceinline__ float lin_act_grad(float g, float yv, int act) {
@@ -248,24 +278,104 @@ __global__ __launch_bounds__(256) void linear_splitm_fold_kernel(const float* __
     }
 }
 
+// ---- Round 5: direct forms of the two backward products for the 64-row squeeze-excitation layers.  The activation gradient g = dy * act'(y)
+// of ONE row (dx) or ONE column (dw) is staged in LDS once per workgroup; the products then run as plain loops with coalesced loads,
+// contraction index ascending with one fused multiply-add per step (the tiled kernel's summation order: same bits).
+// dx[m][k] = sum_n g[m][n] w[n][k] for N <= 128: workgroup = (row m, 256 consecutive k)
+__device__ __forceinline__ void linear_dx_shortn_body(unsigned block, float* gs /* [128] */, const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ w, float* __restrict__ dx, int M, int N, int K, int act) {
+    const unsigned kb = (unsigned)((K + 255) / 256);
+    const int m = (int)(block / kb), k = (int)(block % kb) * 256 + (int)threadIdx.x;
+    if ((int)threadIdx.x < N) {
+        const long long o = (long long)m * N + threadIdx.x;
+        gs[threadIdx.x] = lin_act_grad(dy[o], act ? y[o] : 0.f, act);
+    }
+    __syncthreads();
+    if (k >= K) return;
+    float acc = 0.f;
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+        float wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wv[q] = w[(long long)(n + q) * K + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(gs[n + q], wv[q], acc);
+    }
+    for (; n < N; ++n) acc = fmaf(gs[n], w[(long long)n * K + k], acc);
+    dx[(long long)m * K + k] = acc;
+}
+// dw[n][k] = sum_m g[m][n] x[m][k], db[n] = sum_m g[m][n] for M <= 128: workgroup = NPB output rows n x KT consecutive k (KT = 64 when
+// K <= 64: four rows per workgroup, else 256: one)
+__device__ __forceinline__ void linear_dw_shortm_body(unsigned block, float* gs /* [4][128] */, const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int M, int N, int K,
+                                                      int act, int accumulate) {
+    const int KT = K <= 64 ? 64 : 256, NPB = 256 / KT;
+    const unsigned kb = (unsigned)((K + KT - 1) / KT);
+    const int nl = (int)threadIdx.x / KT, kl = (int)threadIdx.x % KT;
+    const int n0 = (int)(block / kb) * NPB, k = (int)(block % kb) * KT + kl;
+    // column n0 + j of g, j < NPB: M * NPB values, thread t -> (j = t / M, m = t % M) while t < NPB * M (<= 512: two rounds)
+    for (int t = threadIdx.x; t < NPB * M; t += 256) {
+        const int j = t / M, m = t - j * M;
+        const int n = n0 + j;
+        float g = 0.f;
+        if (n < N) {
+            const long long o = (long long)m * N + n;
+            g = lin_act_grad(dy[o], act ? y[o] : 0.f, act);
+        }
+        gs[j * 128 + m] = g;
+    }
+    __syncthreads();
+    const int n = n0 + nl;
+    if (n >= N) return;
+    const float* g1 = gs + nl * 128;
+    if (k < K) {
+        float acc = 0.f;
+        int m = 0;
+        for (; m + 8 <= M; m += 8) {
+            float xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = x[(long long)(m + q) * K + k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fmaf(g1[m + q], xv[q], acc);
+        }
+        for (; m < M; ++m) acc = fmaf(g1[m], x[(long long)m * K + k], acc);
+        const long long o = (long long)n * K + k;
+        dw[o] = accumulate ? dw[o] + acc : acc;
+    }
+    if (db && block % kb == 0 && kl == 0) {
+        float t = 0.f;
+        for (int m = 0; m < M; ++m) t += g1[m];
+        db[n] = accumulate ? db[n] + t : t;
+    }
+}
+
 // dx and dw of one Linear in ONE launch: the two products are independent, but as two launches they ran one after the other -- two chains
 // of latencies on a handful of workgroups each (the squeeze-excitation layers of EfficientNet: 104 such launches, 10-15 us each, per
 // step).  Workgroups [0, nx) compute dx, the rest dw; each side keeps its own kernel shape (64 x 64 tiles or one wave / thread per output).
-template <bool DXT, bool DWT>
+// modes: dx 0 = one wave per output, 1 = 64 x 64 tiles, 2 = short contraction (N <= 128);
+//        dw 0 = one thread per output, 1 = tiles, 2 = short contraction (M <= 128);  -1 = that product is not wanted
+// (Tried for the long contraction with K <= 64 outputs per row -- the second Linear's input gradient, N = 288 .. 2304: one workgroup
+// per row, 64 k lanes x 4 slices of n.  64 workgroups walking N / 4 dependent load batches: 14 - 58 us against 8 - 17 us of one wave per
+// output, whose 3712 waves hide each other's latencies.  Removed.)
+template <int DXM, int DWM>
 __global__ __launch_bounds__(256) void linear_bwd_dual_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
                                                               const float* __restrict__ y, float* __restrict__ dx, float* __restrict__ dw,
                                                               float* __restrict__ db, int M, int N, int K, int act, int accumulate, unsigned nx,
                                                               unsigned dx_gx, unsigned dw_gx) {
-    __shared__ __attribute__((aligned(16))) float At[(DXT || DWT) ? 64 : 1][68];
-    __shared__ __attribute__((aligned(16))) float Bt[(DXT || DWT) ? 64 : 1][68];
+    constexpr bool TILES = DXM == 1 || DWM == 1;
+    __shared__ __attribute__((aligned(16))) float At[TILES ? 64 : 1][68];
+    __shared__ __attribute__((aligned(16))) float Bt[TILES ? 64 : 1][68];
+    __shared__ float gs[(DXM == 2 || DWM == 2) ? 512 : 1];
     unsigned b = blockIdx.x;
     if (b < nx) {
-        if constexpr (DXT) linear_tile_body<1>(At, Bt, b % dx_gx, b / dx_gx, dy, y, w, nullptr, dx, nullptr, M, N, K, act, 0);
-        else linear_dx_body(b, dy, y, w, dx, M, N, K, act);
+        if constexpr (DXM == 1) linear_tile_body<1>(At, Bt, b % dx_gx, b / dx_gx, dy, y, w, nullptr, dx, nullptr, M, N, K, act, 0);
+        else if constexpr (DXM == 2) linear_dx_shortn_body(b, gs, dy, y, w, dx, M, N, K, act);
+        else if constexpr (DXM == 0) linear_dx_body(b, dy, y, w, dx, M, N, K, act);
     } else {
         b -= nx;
-        if constexpr (DWT) linear_tile_body<2>(At, Bt, b % dw_gx, b / dw_gx, dy, y, x, nullptr, dw, db, M, N, K, act, accumulate);
-        else linear_dw_body(b, dy, y, x, dw, db, M, N, K, act, accumulate);
+        if constexpr (DWM == 1) linear_tile_body<2>(At, Bt, b % dw_gx, b / dw_gx, dy, y, x, nullptr, dw, db, M, N, K, act, accumulate);
+        else if constexpr (DWM == 2) linear_dw_shortm_body(b, gs, dy, y, x, dw, db, M, N, K, act, accumulate);
+        else if constexpr (DWM == 0) linear_dw_body(b, dy, y, x, dw, db, M, N, K, act, accumulate);
     }
 }
 
@@ -448,6 +558,11 @@ extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, flo
     CS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long waves = (long long)M * N;
+    if (waves >= 1024 && K <= 64 && waves <= (1LL << 22)) {
+        hipLaunchKernelGGL(linear_fwd_shortk_kernel, dim3((unsigned)((waves + 255) / 256)), dim3(256), 0, st, x, w, b, y, preact, M, N, K, act);
+        CS_LAUNCH_CHECK();
+        return CS_OK;
+    }
     if (waves >= 1024 && lin_use_tiles(M, N, K)) {
         hipLaunchKernelGGL(linear_tiled_kernel<0>, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, x, nullptr, w, b, y,
                            preact, M, N, K, act, 0);
@@ -502,43 +617,38 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
-    if (dx && dw) {
-        CS_CHECK_ARG(w && x, "linear_bwd: dx needs w, dw needs x");
-        const bool dxt = (long long)M * K >= 1024 && lin_use_tiles(M, K, N), dwt = (long long)N * K >= 1024 && lin_use_tiles(N, K, M);
-        const unsigned dx_gx = (unsigned)((M + 63) / 64), dw_gx = (unsigned)((N + 63) / 64), gy = (unsigned)((K + 63) / 64);
-        const unsigned nx = dxt ? dx_gx * gy : (unsigned)(((long long)M * K + 3) / 4);
-        const unsigned nw = dwt ? dw_gx * gy : (unsigned)(((long long)N * K + 255) / 256);
-#define CS_LIN_DUAL(A_, B_)                                                                                                            \
-    hipLaunchKernelGGL((linear_bwd_dual_kernel<A_, B_>), dim3(nx + nw), dim3(256), 0, st, x, w, dy, y, dx, dw, db, M, N, K, act, accumulate, nx, \
-                       dx_gx, dw_gx)
-        if (dxt && dwt) CS_LIN_DUAL(true, true);
-        else if (dxt) CS_LIN_DUAL(true, false);
-        else if (dwt) CS_LIN_DUAL(false, true);
-        else CS_LIN_DUAL(false, false);
-#undef CS_LIN_DUAL
-        CS_LAUNCH_CHECK();
-        return CS_OK;
-    }
+    CS_CHECK_ARG(!dx || w, "linear_bwd: dx needs w");
+    CS_CHECK_ARG(!dw || x, "linear_bwd: dw needs x");
+    // kernel shape of each product (-1: not wanted)
+    int dxm = -1, dwm = -1;
+    unsigned nx = 0, nw = 0;
+    const unsigned dx_gx = (unsigned)((M + 63) / 64), dw_gx = (unsigned)((N + 63) / 64), gy = (unsigned)((K + 63) / 64);
     if (dx) {
-        CS_CHECK_ARG(w, "linear_bwd: dx needs w");
-        const long long waves = (long long)M * K;
-        if (waves >= 1024 && lin_use_tiles(M, K, N))
-            hipLaunchKernelGGL(linear_tiled_kernel<1>, dim3((unsigned)((M + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, dy, y, w, nullptr,
-                               dx, nullptr, M, N, K, act, 0);
-        else
-            hipLaunchKernelGGL(linear_dx_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, dy, y, w, dx, M, N, K, act);
-        CS_LAUNCH_CHECK();
+        if (N <= 128) { dxm = 2; nx = (unsigned)M * (unsigned)((K + 255) / 256); }
+        else if ((long long)M * K >= 1024 && lin_use_tiles(M, K, N)) { dxm = 1; nx = dx_gx * gy; }
+        else { dxm = 0; nx = (unsigned)(((long long)M * K + 3) / 4); }
     }
     if (dw) {
-        CS_CHECK_ARG(x, "linear_bwd: dw needs x");
-        const long long tot = (long long)N * K;
-        if (tot >= 1024 && lin_use_tiles(N, K, M))
-            hipLaunchKernelGGL(linear_tiled_kernel<2>, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, dy, y, x, nullptr,
-                               dw, db, M, N, K, act, accumulate);
-        else
-            hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dy, y, x, dw, db, M, N, K, act, accumulate);
-        CS_LAUNCH_CHECK();
+        if (M <= 128) {
+            const int KT = K <= 64 ? 64 : 256, NPB = 256 / KT;
+            dwm = 2; nw = (unsigned)((N + NPB - 1) / NPB) * (unsigned)((K + KT - 1) / KT);
+        } else if ((long long)N * K >= 1024 && lin_use_tiles(N, K, M)) { dwm = 1; nw = dw_gx * gy; }
+        else { dwm = 0; nw = (unsigned)(((long long)N * K + 255) / 256); }
     }
+#define CS_LIN_DUAL(A_, B_)                                                                                                            \
+    case (A_ + 1) * 4 + (B_ + 1):                                                                                                        \
+        hipLaunchKernelGGL((linear_bwd_dual_kernel<A_, B_>), dim3(nx + nw), dim3(256), 0, st, x, w, dy, y, dx, dw, db, M, N, K, act, accumulate, nx, \
+                           dx_gx, dw_gx);                                                                                                \
+        break
+    switch ((dxm + 1) * 4 + (dwm + 1)) {
+        CS_LIN_DUAL(0, 0); CS_LIN_DUAL(0, 1); CS_LIN_DUAL(0, 2); CS_LIN_DUAL(1, 0); CS_LIN_DUAL(1, 1); CS_LIN_DUAL(1, 2);
+        CS_LIN_DUAL(2, 0); CS_LIN_DUAL(2, 1); CS_LIN_DUAL(2, 2);
+        CS_LIN_DUAL(0, -1); CS_LIN_DUAL(1, -1); CS_LIN_DUAL(2, -1);
+        CS_LIN_DUAL(-1, 0); CS_LIN_DUAL(-1, 1); CS_LIN_DUAL(-1, 2);
+        default: return CS_OK;         // neither product wanted
+    }
+#undef CS_LIN_DUAL
+    CS_LAUNCH_CHECK();
     return CS_OK;
 }
 
