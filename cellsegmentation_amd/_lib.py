@@ -111,6 +111,8 @@ _SIGNATURES = {
     "cs_bn_partial_fold": (c_int, [_P, c_int, c_int, _P, _P]),
     "cs_dwconv_dgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P]),
     "cs_dwconv_wgrad": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P]),
+    "cs_dwconv_wgrad_oihw": (c_int, [POINTER(CsConvGeom), c_int, _P, _P, _P, _P, _P]),
+    "cs_dw_weights_hwc_multi": (c_int, [_P, c_int, ctypes.c_longlong, _P]),
     "cs_dwconv_wgrad_workspace": (ctypes.c_size_t, [POINTER(CsConvGeom)]),
     "cs_se_scale": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "cs_se_scale_bwd": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
 }
 
 // dw[i] = sum_r slab[r][i]: workgroup = 16 columns x 16 row lanes, 8 loads in flight per thread
-__global__ __launch_bounds__(256) void dw_wgrad_fold_kernel(const float* __restrict__ slab, int rows, int ncols, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void dw_wgrad_fold_kernel(const float* __restrict__ slab, int rows, int ncols, float* __restrict__ dw, int chan) {
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float acc = 0.f;
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_fold_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r][cl];
-        dw[c] = t;
+        // column c = tap * C + channel; chan > 0: the parameter's own [C][1][R][S] layout (no permute + copy per depthwise layer afterwards)
+        dw[chan > 0 ? (long long)(c % chan) * (ncols / chan) + c / chan : c] = t;
     }
 }
 
@@ -1196,7 +1197,7 @@ extern "C" size_t cs_dwconv_wgrad_workspace(const CsConvGeom* g) {
     return (size_t)nslab * g->R * g->R * g->C * sizeof(float);
 }
 
-extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, float* workspace, void* stream) {
+static int dwconv_wgrad_impl(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, float* workspace, int chan, void* stream) {
     int rc = check_dw(g, "dwconv_wgrad: bad geometry");
     if (rc) return rc;
     CS_CHECK_ARG(x && dy && dw_hwc && workspace, "dwconv_wgrad: NULL tensor (workspace: cs_dwconv_wgrad_workspace bytes)");
@@ -1220,7 +1221,7 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
         }
 #undef CS_DW_STRIP
         CS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dw_wgrad_fold_kernel, dim3((unsigned)((ncols + 15) / 16)), dim3(256), 0, st, workspace, (int)nblk, ncols, dw_hwc);
+        hipLaunchKernelGGL(dw_wgrad_fold_kernel, dim3((unsigned)((ncols + 15) / 16)), dim3(256), 0, st, workspace, (int)nblk, ncols, dw_hwc, chan);
         CS_LAUNCH_CHECK();
         return CS_OK;
     }
@@ -1237,7 +1238,38 @@ extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, co
         hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, workspace, g->N, g->H, g->W,
                            g->C, g->R, g->stride, g->pad, g->P, g->Q, ppb);
     CS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_wgrad_fold_kernel, dim3((unsigned)((ncols + 15) / 16)), dim3(256), 0, st, workspace, (int)nslab, ncols, dw_hwc);
+    hipLaunchKernelGGL(dw_wgrad_fold_kernel, dim3((unsigned)((ncols + 15) / 16)), dim3(256), 0, st, workspace, (int)nslab, ncols, dw_hwc, chan);
+    CS_LAUNCH_CHECK();
+    return CS_OK;
+}
+
+extern "C" int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, float* workspace, void* stream) {
+    return dwconv_wgrad_impl(g, dtype, x, dy, dw_hwc, workspace, 0, stream);
+}
+extern "C" int cs_dwconv_wgrad_oihw(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_oihw, float* workspace, void* stream) {
+    CS_CHECK_ARG(g && g->C > 0, "dwconv_wgrad_oihw: bad geometry");
+    return dwconv_wgrad_impl(g, dtype, x, dy, dw_oihw, workspace, g->C, stream);
+}
+
+// Depthwise filters [C][1][R][S] (the parameters) -> [R][S][C] (what the depthwise kernels read), ALL layers of a network in one launch:
+// one strided torch copy per layer and step was 26 launches of 4.4 us on EfficientNet-B3.  desc (device): n rows of CsDwStageDesc, `first`
+// ascending; one thread per element.
+__global__ __launch_bounds__(256) void dw_weights_hwc_multi_kernel(const CsDwStageDesc* __restrict__ desc, int n, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    const CsDwStageDesc d = desc[lo];
+    const long long e = i - d.first;                 // destination element: tap * C + c
+    const long long tap = e / d.C, c = e - tap * d.C;
+    d.dst[e] = d.src[c * d.RS + tap];
+}
+extern "C" int cs_dw_weights_hwc_multi(const CsDwStageDesc* desc_dev, int n, long long total, void* stream) {
+    CS_CHECK_ARG(desc_dev && n > 0 && total > 0, "dw_weights_hwc_multi: bad arguments");
+    hipLaunchKernelGGL(dw_weights_hwc_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc_dev, n, total);
     CS_LAUNCH_CHECK();
     return CS_OK;
 }

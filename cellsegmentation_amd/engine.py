@@ -358,6 +358,21 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
         stats_pos[0] += n
         return v
 
+    # depthwise filters: the kernels read [R, S, C]; all layers of the plan restaged from the parameters by one launch per pass
+    # (a permute + strided copy per layer: 26 launches of 4.4 us on EfficientNet-B3)
+    dw_hwc = {}
+    dw_units = [ui_ for ui_, u_ in enumerate(plan.units) if u_.kind == "dw"]
+    if dw_units:
+        ws_ = [plan.units[ui_].conv.weight.detach() for ui_ in dw_units]
+        if all(w_.is_contiguous() and w_.dtype == torch.float32 and w_.dim() == 4 and w_.shape[1] == 1 for w_ in ws_):
+            dpack = plan.__dict__.get("_dw_stage_pack")
+            if dpack is None or dpack.key != tuple(w_.data_ptr() for w_ in ws_):
+                dpack = plan.__dict__["_dw_stage_pack"] = K.DwStagePack(ws_)
+            dpack.run()
+            if capturing:
+                _capture.keep(dpack)
+            dw_hwc = dict(zip(dw_units, dpack.hwc))
+
     for ui, u in enumerate(plan.units):
         if u.kind == "conv":
             x = t[u.src]
@@ -444,7 +459,7 @@ def forward(plan, feeds, dtype, bn_train, save, requires, image_hw=None, input_n
             conv, bn = u.conv, u.bn
             R = conv.kernel_size[0]
             geom = K.make_geom(N, H, W, C, C, R, R, conv.stride[0], conv.padding[0])
-            w_hwc = conv.weight.detach()[:, 0].permute(1, 2, 0).contiguous()
+            w_hwc = dw_hwc[ui] if ui in dw_hwc else conv.weight.detach()[:, 0].permute(1, 2, 0).contiguous()
             if _bn_uses_batch_stats(bn, bn_train):
                 z, zstats = K.dwconv_fwd_stats(geom, x, w_hwc)
                 M = N * geom.P * geom.Q
@@ -830,7 +845,7 @@ def backward(plan, state, grad_feeds, param_needs, requires, use_tr_read=True):
             if need(ui, "beta"):
                 emit(ui, "beta", dbeta)
             if need(ui, "weight"):
-                emit(ui, "weight", K.dwconv_wgrad(a.geom, x, dz).permute(2, 0, 1).unsqueeze(1).contiguous())
+                emit(ui, "weight", K.dwconv_wgrad(a.geom, x, dz, param_layout=True))
             if requires.get(u.src, False):
                 left[u.src] -= 1
                 dx = K.dwconv_dgrad(a.geom, dz, a.w_hwc)

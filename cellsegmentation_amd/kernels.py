@@ -776,12 +776,41 @@ def dwconv_dgrad(geom, dy, w_hwc):
     return dx
 
 
-def dwconv_wgrad(geom, x, dy):
+def dwconv_wgrad(geom, x, dy, param_layout=False):
+    """fp32 [R, S, C]; param_layout: [C, 1, R, S], the layout of nn.Conv2d(groups=C).weight (no permute + copy afterwards)."""
     lib = _lib.load()
-    dw = torch.empty((geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
     ws = torch.empty((max(lib.cs_dwconv_wgrad_workspace(ctypes.byref(geom)) // 4, 1),), dtype=torch.float32, device=x.device)
+    if param_layout:
+        dw = torch.empty((geom.C, 1, geom.R, geom.S), dtype=torch.float32, device=x.device)
+        _lib.check(lib.cs_dwconv_wgrad_oihw(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "dwconv_wgrad_oihw")
+        return dw
+    dw = torch.empty((geom.R, geom.S, geom.C), dtype=torch.float32, device=x.device)
     _lib.check(lib.cs_dwconv_wgrad(ctypes.byref(geom), _code(x.dtype), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "dwconv_wgrad")
     return dw
+
+
+class DwStagePack:
+    """The depthwise filters of a plan in the layout the depthwise kernels read ([R, S, C] fp32), restaged from the parameters by ONE launch
+    per forward (cs_dw_weights_hwc_multi).  `weights`: the nn.Conv2d(groups=C).weight parameters, [C, 1, R, S] fp32 contiguous."""
+
+    def __init__(self, weights):
+        dev = weights[0].device
+        sizes = [w.numel() for w in weights]
+        self.flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+        self.key = tuple(w.data_ptr() for w in weights)
+        self.hwc, rows, first = [], [], 0
+        for w, n in zip(weights, sizes):
+            C, RS = w.shape[0], w.shape[2] * w.shape[3]
+            dst = self.flat[first:first + n].view(w.shape[2], w.shape[3], C)
+            self.hwc.append(dst)
+            rows.append([w.data_ptr(), dst.data_ptr(), C, RS, first])
+            first += n
+        self.total = first
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.n = len(rows)
+
+    def run(self):
+        _lib.check(_lib.load().cs_dw_weights_hwc_multi(_p(self.desc), self.n, self.total, _stream()), "dw_weights_hwc_multi")
 
 
 def se_scale(x, s):

@@ -325,6 +325,13 @@ int cs_dwconv_dgrad(const CsConvGeom* g, int dtype, const void* dy, const float*
  * overwritten, not accumulated into) */
 size_t cs_dwconv_wgrad_workspace(const CsConvGeom* g);
 int cs_dwconv_wgrad(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_hwc, float* workspace, void* stream);
+/* the same with the result in the parameter's own layout [C][1][R][S] (nn.Conv2d(groups = C).weight, model/efficientnet.py:97-103) */
+int cs_dwconv_wgrad_oihw(const CsConvGeom* g, int dtype, const void* x, const void* dy, float* dw_oihw, float* workspace, void* stream);
+/* Depthwise filters of MANY layers, parameter layout [C][1][R][S] -> the [R][S][C] the depthwise kernels read, in one launch.
+ * desc_dev: n rows in DEVICE memory, `first` (offset of the layer's first element in the launch's flat index space) ascending;
+ * total = sum of C * RS. */
+typedef struct { const float* src; float* dst; long long C; long long RS; long long first; } CsDwStageDesc;
+int cs_dw_weights_hwc_multi(const CsDwStageDesc* desc_dev, int n, long long total, void* stream);
 /* y[n][p][c] = x[n][p][c]*s[n][c] */
 int cs_se_scale(const void* x, int dtype, const float* s, void* y, int N, int HW, int C, void* stream);
 /* phase 0: ds[n][c] = sum_p dy*x ; phase 1: dx = dy*s + davg[n][c]/HW (davg nullable) */
