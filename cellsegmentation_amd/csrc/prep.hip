@@ -630,13 +630,14 @@ __global__ __launch_bounds__(NT) void wgrad_finalize_fused_kernel(FinalizeTables
             float raw = 0.f;
             if (c < Cin) {
                 const float* src = raw_p + (long long)k * Cp + c;
-                int s = sl;
-                for (; s + 3 * SL < nsplit; s += 4 * SL) {
-                    const float a0 = src[(long long)s * slab_stride], a1 = src[(long long)(s + SL) * slab_stride];
-                    const float a2 = src[(long long)(s + 2 * SL) * slab_stride], a3 = src[(long long)(s + 3 * SL) * slab_stride];
-                    raw += (a0 + a1) + (a2 + a3);
+                // eight slabs in flight per thread, the tail predicated instead of walked one load at a time (6 splits were 4 + 1 + 1:
+                // three memory round trips)
+                for (int s = sl; s < nsplit; s += 8 * SL) {
+                    float a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = (s + u * SL < nsplit) ? src[(long long)(s + u * SL) * slab_stride] : 0.f;
+                    raw += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
                 }
-                for (; s < nsplit; s += SL) raw += src[(long long)s * slab_stride];
             }
             if (SL > 1) {
                 __syncthreads();
@@ -660,8 +661,12 @@ __global__ __launch_bounds__(NT) void wgrad_finalize_fused_kernel(FinalizeTables
                 float raw = 0.f;
                 if (cl < cw) {
                     const float* src = raw_p + ((long long)k * RS + rs) * Cp + c0 + cl;
-#pragma unroll 4
-                    for (int s = 0; s < nsplit; ++s) raw += src[(long long)s * slab_stride];
+                    for (int s = 0; s < nsplit; s += 8) {
+                        float a[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) a[u] = (s + u < nsplit) ? src[(long long)(s + u) * slab_stride] : 0.f;
+                        raw += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+                    }
                 }
                 tile[rs * (kFinCT + 1) + cl] = raw;
             }
