@@ -247,9 +247,22 @@ __global__ __launch_bounds__(256) void stage_conv_bn_multi_kernel(const CsStageD
         for (int tile = b; tile < n_tiles; tile += nb) {
             const int k0 = (tile / n_ct) * 16, c0 = (tile % n_ct) * 64;
             __syncthreads();
-            for (int idx = threadIdx.x; idx < 16 * run; idx += 256) {
-                const int r = idx / run, o = idx - r * run;
-                tile_s[r][o] = d.w[((long long)(k0 + r) * d.Cin + c0) * RS + o];
+            // eight loads in flight per thread, then their LDS stores (written load, store, load, store ... hipcc waits for every load before
+            // its store: 36 memory round trips per 3x3 tile and thread; the launch ran at 2.2 TB/s)
+            for (int idx0 = threadIdx.x; idx0 < 16 * run; idx0 += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = idx0 + 256 * u;
+                    const int r = idx / run, o = idx - r * run;
+                    v[u] = idx < 16 * run ? d.w[((long long)(k0 + r) * d.Cin + c0) * RS + o] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = idx0 + 256 * u;
+                    const int r = idx / run, o = idx - r * run;
+                    if (idx < 16 * run) tile_s[r][o] = v[u];
+                }
             }
             if (threadIdx.x < 16) {
                 const int k = k0 + threadIdx.x;
