@@ -370,13 +370,14 @@ def fp32_parity_mode_rate(dev, x, labels, steps=5, warmup=2):
 
 
 def secondary_configs(timeout_s=240):
-    """N = 1 only, outside the timed region: short runs of the other BASELINE.json configs (C1 as one HIP graph, C4 EfficientNet-B3,
-    C5 segmentation at 299 and 512) in a CHILD process (tools/bench_configs.py: its own models and allocator; started, never exec'd),
+    """N = 1 only, outside the timed region: short runs of the other BASELINE.json configs (C1, C4 EfficientNet-B3, C5 segmentation at 299
+    and 512; C1 / C4 / C5 both enqueued from Python and replayed as one HIP graph -- the EfficientNet step is ~1900 launches, and once its
+    GPU time fell to 17 ms the eager figure became the HOST's on boxes that need longer than that to enqueue them) in a CHILD process (tools/bench_configs.py: its own models and allocator; started, never exec'd),
     so that the driver's record carries their throughput and the roofline of their dominant conv kernel next to the headline.
     Never `value`."""
     import subprocess
     env = dict(os.environ, STEPS="6", ROOFLINE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c1", "c1api", "c4", "c5", "c5x"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "c1", "c1api", "c4", "c4g", "c5", "c5g", "c5x"], capture_output=True, text=True,
                        timeout=timeout_s, env=env, cwd=ROOT)
     out = []
     for line in r.stdout.splitlines():

@@ -229,7 +229,7 @@ if "c4" in which:
         opt.zero_grad(set_to_none=True)
         HF.cross_entropy(m(x, freeze_bn=True), y).backward()
         opt.step()
-    run("c4 efficientnet_b3 tile bag=64 bf16 (fwd+bwd+Adam, BN train)", s4, 64, "tiles/s", roofline_cfg="c4")
+    run("c4 efficientnet_b3 tile bag=64 bf16 (fwd+bwd+Adam, BN train), enqueued from Python (~1900 launches per step: host-bound on slow hosts, see c4g)", s4, 64, "tiles/s", roofline_cfg="c4")
     # roofline entry of C4's dominant kernel family (profiles/round3_efficientnet_b3_kernel_stats.md: bn_bwd_reduce_kernel + bn_bwd_apply_kernel,
     # 78 train-mode BatchNorms): HIP events around every BN backward of three more steps; algorithmic bytes = the reduction reads dy and z,
     # the apply pass reads them again and writes dz: 5 passes over an M x C bf16 tensor; HBM-bound by construction
