@@ -45,16 +45,23 @@ def main():
         w = torch.randn((k, k, C), device=dev)
         res = {}
         for name, fn in (("fwd", lambda: K.dwconv_fwd_stats(g, x, w)), ("dgrad", lambda: K.dwconv_dgrad(g, dy, w)), ("wgrad", lambda: K.dwconv_wgrad(g, x, dy))):
+            # GPU time: `iters` calls captured into one HIP graph and replayed (event-timed Python calls measure the wrapper on small maps)
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(iters):
+                    fn()
+            gr.replay()
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(iters):
-                fn()
+            for _ in range(3):
+                gr.replay()
             e1.record()
             torch.cuda.synchronize()
-            res[name] = e0.elapsed_time(e1) / iters
+            res[name] = e0.elapsed_time(e1) / (3 * iters)
             tot[name] += res[name] * cnt
         by = (x.numel() + dy.numel()) * 2
         print(f"C{C:5d} k{k} s{s} H{H:4d} x{cnt}  " + "  ".join(f"{n}: {ms * 1e3:7.1f} us {by / ms / 1e6:6.0f} GB/s" for n, ms in res.items()) + f"   {by / 1e6:6.1f} MB", flush=True)
