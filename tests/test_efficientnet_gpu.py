@@ -275,3 +275,27 @@ def test_bn_apply_stats_equals_finalize_then_apply(shape, act):
     assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
     assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
     assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+
+
+def test_depthwise_filter_staging_and_parameter_layout_gradient(dev):
+    """kernels.DwStagePack (cs_dw_weights_hwc_multi): the filters of several layers, parameter layout [C, 1, R, S] -> [R, S, C], in one launch,
+    bit for bit the permute + copy it replaces; cs_dwconv_wgrad_oihw: the weight gradient in the parameter's layout equals the [R, S, C]
+    one permuted (model/efficientnet.py:97-103: nn.Conv2d(groups = C))."""
+    g = torch.Generator().manual_seed(11)
+    ws = [torch.randn((c, 1, r, r), generator=g).to(dev) for c, r in ((40, 3), (144, 3), (288, 5), (8, 5), (2304, 3))]
+    pack = K.DwStagePack(ws)
+    pack.run()
+    torch.cuda.synchronize()
+    for w, hwc in zip(ws, pack.hwc):
+        assert torch.equal(hwc, w[:, 0].permute(1, 2, 0).contiguous())
+    ws[1].mul_(2.0)                      # an optimizer update in place: the next launch restages it
+    pack.run()
+    assert torch.equal(pack.hwc[1], ws[1][:, 0].permute(1, 2, 0).contiguous())
+    for (n, h, c, r, s) in ((4, 19, 144, 5, 1), (3, 20, 48, 3, 2), (2, 10, 816, 5, 1)):
+        geom = K.make_geom(n, h, h, c, c, r, r, s, (r - 1) // 2)
+        x = torch.randn((n, h, h, c), generator=g).to(torch.bfloat16).to(dev)
+        dy = torch.randn((n, geom.P, geom.Q, c), generator=g).to(torch.bfloat16).to(dev)
+        a = K.dwconv_wgrad(geom, x, dy)
+        b = K.dwconv_wgrad(geom, x, dy, param_layout=True)
+        assert tuple(b.shape) == (c, 1, r, r)
+        assert torch.equal(b, a.permute(2, 0, 1).unsqueeze(1).contiguous())
