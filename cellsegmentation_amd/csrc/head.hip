@@ -558,7 +558,8 @@ extern "C" int cs_linear_fwd(const float* x, const float* w, const float* b, flo
     CS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long long waves = (long long)M * N;
-    if (waves >= 1024 && K <= 64 && waves <= (1LL << 22)) {
+    static const int direct = cs_env_int_("CELLSEG_LINEAR_DIRECT", 1);       // A/B flavour only (0: the tiles everywhere they used to run)
+    if (direct && waves >= 1024 && K <= 64 && waves <= (1LL << 22)) {
         hipLaunchKernelGGL(linear_fwd_shortk_kernel, dim3((unsigned)((waves + 255) / 256)), dim3(256), 0, st, x, w, b, y, preact, M, N, K, act);
         CS_LAUNCH_CHECK();
         return CS_OK;
@@ -620,16 +621,17 @@ extern "C" int cs_linear_bwd(const float* x, const float* w, const float* dy, co
     CS_CHECK_ARG(!dx || w, "linear_bwd: dx needs w");
     CS_CHECK_ARG(!dw || x, "linear_bwd: dw needs x");
     // kernel shape of each product (-1: not wanted)
+    static const int direct = cs_env_int_("CELLSEG_LINEAR_DIRECT", 1);       // A/B flavour only
     int dxm = -1, dwm = -1;
     unsigned nx = 0, nw = 0;
     const unsigned dx_gx = (unsigned)((M + 63) / 64), dw_gx = (unsigned)((N + 63) / 64), gy = (unsigned)((K + 63) / 64);
     if (dx) {
-        if (N <= 128) { dxm = 2; nx = (unsigned)M * (unsigned)((K + 255) / 256); }
+        if (direct && N <= 128) { dxm = 2; nx = (unsigned)M * (unsigned)((K + 255) / 256); }
         else if ((long long)M * K >= 1024 && lin_use_tiles(M, K, N)) { dxm = 1; nx = dx_gx * gy; }
         else { dxm = 0; nx = (unsigned)(((long long)M * K + 3) / 4); }
     }
     if (dw) {
-        if (M <= 128) {
+        if (direct && M <= 128) {
             const int KT = K <= 64 ? 64 : 256, NPB = 256 / KT;
             dwm = 2; nw = (unsigned)((N + NPB - 1) / NPB) * (unsigned)((K + KT - 1) / KT);
         } else if ((long long)N * K >= 1024 && lin_use_tiles(N, K, M)) { dwm = 1; nw = dw_gx * gy; }

@@ -277,3 +277,46 @@ def test_positive_bits_plane(dev):
     assert torch.equal(got_words, words)
     assert torch.equal(K.unpack_bits(bits, 96), xb.float() > 0)
     assert torch.equal(K.pack_bits(xb.float() > 0), bits)
+
+
+def _linear_products(dev):
+    """fwd / bwd of the squeeze-excitation shapes (64 rows) as raw bytes, seeded."""
+    import hashlib
+    out = []
+    for (M, C, Q) in ((64, 576, 24), (64, 1392, 58), (64, 40, 10), (33, 144, 6)):
+        g = torch.Generator().manual_seed(M * 7 + C)
+        x = torch.randn((M, C), generator=g).to(dev)
+        w1, b1 = (torch.randn((Q, C), generator=g) * 0.05).to(dev), torch.randn((Q,), generator=g).to(dev)
+        w2, b2 = (torch.randn((C, Q), generator=g) * 0.05).to(dev), torch.randn((C,), generator=g).to(dev)
+        h, pre = K.linear_fwd(x, w1, b1, K.CS_ACT_SILU, want_preact=True)
+        s = K.linear_fwd(h, w2, b2, K.CS_ACT_SIGMOID)
+        g2, g1 = torch.randn((M, C), generator=g).to(dev), torch.randn((M, Q), generator=g).to(dev)
+        r2 = K.linear_bwd(h, w2, g2, s, K.CS_ACT_SIGMOID)
+        r1 = K.linear_bwd(x, w1, g1, pre, K.CS_ACT_SILU)
+        torch.cuda.synchronize()
+        for t in (h, pre, s) + tuple(r2) + tuple(r1):
+            out.append(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest())
+    return out
+
+
+def test_direct_linear_kernels_give_the_bits_of_the_tiles(dev):
+    """The direct kernels of the short contractions (linear_fwd_shortk_kernel, linear_dx_shortn_body, linear_dw_shortm_body, csrc/head.hip)
+    accumulate in the order of the 64 x 64 tiles they replace: the production library (direct kernels) and the A/B flavour with
+    CELLSEG_LINEAR_DIRECT=0 (tiles) must give the same bytes.  model/efficientnet.py:62-80 (SqueezeExcitation.fc1 / fc2)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from cellsegmentation_amd import _lib
+    if _lib.FLAVOUR != "":
+        pytest.skip("parent of the A/B comparison runs on the production library")
+    mine = _linear_products(dev)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_pool_head_topk_gpu as T; "
+            "print('BITS', json.dumps(T._linear_products(torch.device('cuda:0'))))") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, CELLSEG_LIB_FLAVOUR="ab", CELLSEG_LINEAR_DIRECT="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("BITS ")][-1]
+    theirs = json.loads(line[5:])
+    assert mine == theirs
